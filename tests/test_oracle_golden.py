@@ -1,0 +1,120 @@
+"""Pin the CPU oracle (oracle/siren_oracle.py) against outputs of the reference itself.
+
+The fixtures under tests/golden/ were produced by oracle/gen_fixtures.py, which imports
+MatteoWohlrapp/mri-inr in the build container and runs its own ModulatedSiren / tiling /
+configuration code on weights and inputs drawn from mri_inr_amd.synthetic seeds.
+Tolerance for the fp32 restatement: 1e-5 normalised (measured ~2e-6).
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, nerr
+from mri_inr_amd import synthetic as syn
+from oracle import siren_oracle as orc
+
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_tiny_layers(act):
+    g = load_golden(f"tiny_{act}.npz")
+    meta = json.loads(str(g["meta"]))
+    sd = syn.make_state_dict(seed=meta["seed"], dim_hidden=meta["H"], num_layers=meta["L"],
+                             latent_dim=meta["Z"], siren_patch_size=meta["S"])
+    mods = syn.make_mods(meta["mods_seed"], meta["L"], meta["B"], meta["H"])
+    out, hid = orc.siren_forward(sd, mods, num_layers=meta["L"], activation=act,
+                                 siren_patch_size=meta["S"], return_hidden=True)
+    for l in range(meta["L"]):
+        assert nerr(hid[l], g[f"hidden{l}"]) < TOL, l
+    assert nerr(out, g["out"]) < TOL
+    out64 = orc.siren_forward(sd, mods, num_layers=meta["L"], activation=act,
+                              siren_patch_size=meta["S"], dtype=np.float64)
+    assert nerr(out64, g["out"]) < 2e-5
+
+
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_trunk_default_shape(act):
+    g = load_golden(f"trunk_{act}.npz")
+    meta = json.loads(str(g["meta"]))
+    sd = syn.make_state_dict(seed=meta["seed"])
+    L, H = meta["L"], meta["H"]
+    kw = dict(num_layers=L, activation=act)
+    assert nerr(orc.siren_forward(sd, syn.make_mods(31, L, 1, H), **kw), g["uniform_B1"]) < TOL
+    assert nerr(orc.siren_forward(sd, syn.make_mods(32, L, 64, H), **kw), g["uniform_B64"]) < TOL
+    sparse = syn.make_mods(33, L, 16, H, lo=0.0, hi=2.0, zero_fraction=0.5)
+    assert nerr(orc.siren_forward(sd, sparse, **kw), g["sparse_B16"]) < TOL
+    assert nerr(orc.siren_forward(sd, g["modulator_mods"], **kw), g["modulator_B16"]) < TOL
+
+
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_encoder_and_modulator(act):
+    g = load_golden(f"trunk_{act}.npz")
+    sd = syn.make_state_dict(seed=7)
+    tiles = np.random.default_rng(41).random((16, 32, 32), dtype=np.float32)
+    z = orc.encoder_forward(sd, tiles)
+    assert nerr(z, g["modulator_latent"]) < TOL
+    mods = orc.modulator_forward(sd, g["modulator_latent"], num_layers=5)
+    assert nerr(mods, g["modulator_mods"]) < TOL
+    assert (mods >= 0).all()
+
+
+@pytest.mark.parametrize("preset", ["default", "trained"])
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_full_forward(preset, act):
+    g = load_golden(f"forward_{preset}_{act}.npz")
+    sd = syn.make_state_dict(seed=7, trained_like=(preset == "trained"))
+    tiles = np.random.default_rng(42).random((8, 32, 32), dtype=np.float32)
+    assert nerr(orc.encoder_forward(sd, tiles), g["latent"]) < TOL
+    assert nerr(orc.modulator_forward(sd, g["latent"], num_layers=5), g["mods"]) < TOL
+    out = orc.modulated_siren_forward(sd, tiles, num_layers=5, activation=act)
+    assert out.shape == (8, 24, 24) and out.dtype == np.float32
+    # the trained-like preset spans [-1,1] through 5 sine layers: chaotic amplification of the
+    # encoder/modulator rounding differences is part of the reference's own fp32 noise floor
+    assert nerr(out, g["out"]) < (5e-5 if preset == "trained" else TOL)
+
+
+def test_fp32_noise_floor_of_reference():
+    """How far is the reference (torch fp32) from exact arithmetic?  Sizes the 1e-4 GPU gate."""
+    g = load_golden("trunk_sine.npz")
+    sd = syn.make_state_dict(seed=7)
+    ref64 = orc.siren_forward(sd, syn.make_mods(32, 5, 64, 256), num_layers=5, dtype=np.float64)
+    e = nerr(g["uniform_B64"], ref64)
+    assert e < 3e-5, e
+
+
+def test_tiling_known_answers():
+    g = load_golden("tiling.npz")
+    for name, (hh, ww) in (("320x320", (320, 320)), ("70x50", (70, 50))):
+        img = syn.make_slice(3, hh, ww, brain_mask=(name == "320x320"))
+        patches, info = orc.image_to_patches(img, 32, 16)
+        assert tuple(info) == tuple(g[f"info_{name}"])
+        assert np.array_equal(patches, g[f"patches_{name}"])
+        kept, black, shape = orc.filter_and_remember_black_patches(patches)
+        assert black == list(g[f"black_{name}"])
+        rec = np.random.default_rng(5).random((patches.shape[0], 24, 24), dtype=np.float32)
+        wf = orc.patches_to_image_weighted_average(rec, info, 24, 16)
+        assert wf.shape == g[f"wfold_{name}"].shape[1:]
+        assert nerr(wf, g[f"wfold_{name}"][0]) < 1e-6
+        assert nerr(orc.patches_to_image(patches, info, 32, 16), g[f"fold_{name}"][0]) < 1e-6
+        keep = [i for i in range(patches.shape[0]) if i not in black]
+        assert np.array_equal(orc.reintegrate_black_patches(rec[keep], black, shape), g[f"reint_{name}"])
+        assert np.array_equal(orc.extract_center_batch(patches, 32, 24), g[f"center_{name}"])
+    assert nerr(orc.generate_weight_matrix(24), g["weight_matrix_24"]) < 1e-7
+    assert nerr(orc.generate_weight_matrix(32), g["weight_matrix_32"]) < 1e-7
+    # known answers recorded in SURVEY.md §8(f)
+    p, info = orc.image_to_patches(syn.make_slice(3, 70, 50), 32, 16)
+    assert p.shape == (20, 32, 32) and info == (5, 4)
+    w = orc.generate_weight_matrix(24)
+    assert abs(w[0, 0] - 0.211055) < 1e-5 and w[11, 11] == 1.0 and w[12, 12] == 1.0
+
+
+def test_slice_reconstruction():
+    g = load_golden("slice_recon.npz")
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    img = syn.make_slice(0, 160, 128, brain_mask=True)
+    rec = orc.reconstruct_slice(sd, img, num_layers=5)
+    assert rec.shape == g["image"].shape[1:]
+    assert len(g["black"]) > 0
+    assert nerr(rec, g["image"][0]) < 5e-5
