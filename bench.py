@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X modulated-SIREN path: Mpixels/s reconstructed (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input per GPU:
+``ModulatedSiren.forward`` (encoder -> modulator -> fused SIREN trunk) on the 400 tiles
+(32x32 in, 24x24 out) of ``--slices`` 320x320 slice(s) (default 1 = BASELINE.json configs[1]),
+tiles already resident in HBM, outputs left in HBM.  Patches are independent, so with N GPUs
+every rank processes its own slices (weak scaling); the only collective on the path is the RCCL
+broadcast of the weight blob from rank 0 at load time, outside the timed region.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement for the fields).
+torch is used for process-group plumbing (RCCL/gloo) and device synchronisation only.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (= vector peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--slices", type=int, default=1, help="320x320 slices per GPU per step")
+    ap.add_argument("--activation", default="sine", choices=["sine", "morlet"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
+    ap.add_argument("--check", action="store_true", help="also verify one batch against the oracle")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, tiles, activation, budget_s):
+    """The torch-CPU twin (oracle/torch_twin.py, "port") timed on this box's host cores."""
+    import torch
+
+    from oracle import torch_twin as tw
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    t = tw.to_tensors(sd)
+    x = torch.from_numpy(tiles)
+    tw.forward_tiles(t, x[:64], num_layers=5, activation=activation)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tw.forward_tiles(t, x, num_layers=5, activation=activation)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    px = n * 320 * 320
+    return {
+        "value": px / el / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port",
+        "sample": f"{n} x (one 320x320 slice = 400 tiles -> 400x24x24) through oracle/torch_twin.py "
+                  f"(torch {torch.__version__} CPU, {torch.get_num_threads()} threads), {el:.1f} s",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    from mri_inr_amd import ModulatedSiren, synthetic as syn
+    from mri_inr_amd import _lib
+    from mri_inr_amd.dist import broadcast_state_dict
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a gfx950 GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- model: random-init weights of the named architecture; rank 0's copy is broadcast (RCCL) ----
+    sd = syn.make_state_dict(seed=7, trained_like=True) if rank == 0 else None
+    sd = broadcast_state_dict(sd, src=0, device=torch.device("cuda", local_rank)) if world > 1 else sd
+    model = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
+                           use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                           outer_patch_size=32, inner_patch_size=16, siren_patch_size=24,
+                           device=f"cuda:{local_rank}", activation=args.activation)
+    model.load_state_dict(sd)
+    model.to(f"cuda:{local_rank}").eval()
+    lib, h = model._lib, model._h
+
+    # ---- synthetic input: slice k = default_rng(1000+k).random((320,320)), tiled 32/16 on the device ----
+    n_sl = args.slices
+    imgs = np.stack([syn.make_slice(rank * n_sl + k) for k in range(n_sl)])
+    B = n_sl * 400
+    d_img = model.device_array(imgs.shape).copy_from(imgs)
+    d_tiles = model.device_array((B, 32, 32))
+    d_out = model.device_array((B, 24, 24))
+    _lib.check(lib.msiren_image_to_patches_dev(h, d_img.ptr, n_sl, 320, 320, d_tiles.ptr))
+    model.sync()
+
+    def step():
+        _lib.check(lib.msiren_forward_tiles_dev(h, d_tiles.ptr, B, d_out.ptr))
+
+    def fence():
+        model.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    import ctypes as C
+
+    _lib.check(lib.msiren_profile_enable(h, 1))  # HIP events around every trunk launch, on its stream
+    _lib.check(lib.msiren_timer_start(h))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    model.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    dev_ms = C.c_float()
+    _lib.check(lib.msiren_timer_stop(h, C.byref(dev_ms)))
+    launches, trunk_ms = C.c_int64(), C.c_double()
+    _lib.check(lib.msiren_profile_read(h, C.byref(launches), C.byref(trunk_ms)))
+    _lib.check(lib.msiren_profile_enable(h, 0))
+    elapsed = t1 - t0
+    if world > 1:
+        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    px_per_step = world * n_sl * 320 * 320
+    value = px_per_step * args.steps / elapsed / 1e6
+    flops_launch = model.flops_per_coord() * B * 576
+    trunk_avg_s = trunk_ms.value / max(launches.value, 1) / 1e3
+    achieved = flops_launch / trunk_avg_s / 1e12
+
+    result = {
+        "metric": "Mpixels/sec reconstructed (320x320 slice, hidden=256, 5 layers)",
+        "value": value, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[1]: {n_sl} x 320x320 slice per GPU per step -> {B} tiles 32x32 -> "
+                        f"ModulatedSiren.forward (encoder+modulator+fused trunk, {args.activation}) -> {B}x24x24; "
+                        "tiles and outputs resident in HBM",
+            "slices_per_gpu_per_step": n_sl, "patches_per_step_per_gpu": B, "coords_per_patch": 576,
+            "dim_hidden": 256, "num_layers": 5, "activation": args.activation, "parallelism": f"patch-shard x{world}",
+        },
+        "roofline": {
+            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "siren_trunk_f32_kernel<256,%d,0>" % (1 if args.activation == "morlet" else 0),
+            "flops_per_launch": flops_launch, "avg_launch_ms": trunk_avg_s * 1e3, "launches": int(launches.value),
+        },
+        "device_ms_per_step": dev_ms.value / args.steps,
+    }
+
+    if rank == 0:
+        if args.check:
+            from oracle import siren_oracle as orc
+
+            got = d_out.numpy()[:64]
+            tiles_h = d_tiles.numpy()[:64]
+            ref = orc.modulated_siren_forward(sd, tiles_h, num_layers=5, activation=args.activation, dtype=np.float64)
+            result["check_nerr_vs_fp64_oracle"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd, d_tiles.numpy()[:400], args.activation, args.cpu_seconds)
+        else:
+            result["cpu_baseline"] = None
+        info = model.device_info()
+        result["device"] = info["name"]
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+/*
+ * msiren.h -- C ABI of libmsiren.so: the MI355X (gfx950) modulated-SIREN inference path.
+ *
+ * Drop-in boundary for ONE path of MatteoWohlrapp/mri-inr: the dense coordinate-grid forward of
+ * `ModulatedSiren` (reference: src/networks/modulated_siren.py:435-457 and everything it calls).
+ * The reference has no FFI of its own -- its boundary is the Python nn.Module protocol
+ * (ctor kwargs / load_state_dict / __call__) -- so every entry point below names the reference
+ * interface it stands in for.  The Python mirror of that protocol (mri_inr_amd/model.py) binds
+ * these symbols with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; all tensors are dense row-major float32 unless stated otherwise;
+ *   - every function returns 0 on success, a negative MSIREN_E_* code on failure, and leaves a
+ *     human-readable message retrievable with msiren_last_error() (thread-local);
+ *   - "host" pointers are ordinary process memory; "dev" pointers are HIP device memory on the
+ *     handle's device (hipMalloc, msiren_dev_alloc or e.g. torch.Tensor.data_ptr());
+ *   - *_dev entry points only enqueue work on the handle's stream: call msiren_sync() (or
+ *     msiren_timer_stop()) before reading results;
+ *   - one handle = one device + one stream + one weight set; handles are independent and may be
+ *     used from different threads (a single handle is not re-entrant).
+ */
+#ifndef MSIREN_H
+#define MSIREN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSIREN_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define MSIREN_API __attribute__((visibility("default")))
+#else
+#define MSIREN_API
+#endif
+
+enum {
+    MSIREN_OK = 0,
+    MSIREN_E_INVALID = -1,  /* bad argument / unsupported configuration (Python: ValueError)  */
+    MSIREN_E_STATE = -2,    /* call order: weights missing or not committed (RuntimeError)    */
+    MSIREN_E_SHAPE = -3,    /* tensor size does not match the configuration (load_state_dict) */
+    MSIREN_E_HIP = -4,      /* HIP runtime error (message carries hipGetErrorString)          */
+    MSIREN_E_NOMEM = -5
+};
+
+enum { MSIREN_ACT_SINE = 0, MSIREN_ACT_MORLET = 1 };
+
+/* arithmetic of the hidden-layer contractions */
+enum {
+    MSIREN_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32, the parity path (configs 1-4) */
+    MSIREN_PREC_BF16 = 1  /* bf16 operands, fp32 accumulate (config 5; own tolerance)          */
+};
+
+/*
+ * Mirrors the keyword arguments of ModulatedSiren.__init__ (src/networks/modulated_siren.py:349-368)
+ * that influence the forward pass, i.e. the `model:` block of the YAML files
+ * (configuration/train_modulated_siren.yaml:14-29).  `dropout`, `modulate`, `encoder_path`
+ * have no effect on eval-mode maths and stay on the Python side.
+ */
+typedef struct msiren_config {
+    int32_t abi_version;      /* MSIREN_ABI_VERSION                                             */
+    int32_t dim_in;           /* must be 2 (the grid is a 2-D meshgrid, :427-433)               */
+    int32_t dim_hidden;       /* H                                                              */
+    int32_t dim_out;          /* must be 1 (squeeze(2)+rearrange at :451-455)                   */
+    int32_t num_layers;       /* L: number of modulated sine layers before last_layer           */
+    int32_t latent_dim;       /* Z                                                              */
+    float w0;                 /* frequency of layers 1..L-1 and of last_layer (:196, :211-213)  */
+    float w0_initial;         /* frequency of layer 0                                           */
+    int32_t use_bias;
+    int32_t activation;       /* MSIREN_ACT_*; last_layer is always sine (:120-123)             */
+    int32_t outer_patch_size; /* O: encoder tile (32: FixedAutoencoder is hard-wired to it)     */
+    int32_t inner_patch_size; /* I: tiling stride                                               */
+    int32_t siren_patch_size; /* S: output tile, P = S*S coordinates per patch                  */
+    int32_t residual;         /* 0 = reference semantics; 1 = build-defined skip    */
+    int32_t precision;        /* MSIREN_PREC_*                                                  */
+    int32_t device;           /* HIP device ordinal                                             */
+    int32_t reserved[4];
+} msiren_config;
+
+typedef struct msiren_ctx* msiren_handle;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+
+/* ModulatedSiren(**kwargs) + .to(device): validates the configuration, selects the device,
+ * creates the stream.  Reference: modulated_siren.py:349-433, test_mod_siren.py:96-120. */
+MSIREN_API int msiren_create(const msiren_config* cfg, msiren_handle* out);
+MSIREN_API int msiren_destroy(msiren_handle h);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+MSIREN_API const char* msiren_last_error(void);
+
+/* ---- weights: load_state_dict (test_mod_siren.py:116-118) ------------------------------------ */
+
+/* One state_dict entry, by its reference key name, e.g.
+ *   "net.layers.0.weight" (H,2) ... "net.layers.{l}.weight" (H,H), "net.layers.{l}.bias" (H),
+ *   "net.last_layer.weight" (1,H), "net.last_layer.bias" (1), "grid" (P,2),
+ *   "modulator.layers.{l}.0.weight" (H,Z) / (H,H+Z), "modulator.layers.{l}.0.bias" (H),
+ *   "encoder.encoder.encoder.{0,2,4}.weight/.bias", "encoder.encoder.encoder.7.weight/.bias".
+ * `n` is the element count and must match the shape implied by the configuration
+ * (MSIREN_E_SHAPE otherwise, like load_state_dict's size-mismatch error); unknown names are
+ * MSIREN_E_INVALID ("unexpected key").  Data is copied; the caller keeps ownership. */
+MSIREN_API int msiren_set_tensor(msiren_handle h, const char* name, const float* host_data, size_t n);
+
+/* Packs the tensors into the kernels' layouts and uploads them.  Fails with MSIREN_E_STATE and a
+ * list of missing keys if the trunk ("net.*") is incomplete; modulator / encoder keys are only
+ * required by msiren_forward_latent / msiren_forward_tiles. */
+MSIREN_API int msiren_commit_weights(msiren_handle h);
+
+/* ---- forward ---------------------------------------------------------------------------------- */
+
+/* SirenNet.forward over the fixed grid (modulated_siren.py:215-233 + :448-455):
+ * mods (L,B,H) -- the tuple the Modulator returns, stacked -- -> out (B,S,S).  B may be 0. */
+MSIREN_API int msiren_forward_mods(msiren_handle h, const float* mods_host, int64_t B, float* out_host);
+MSIREN_API int msiren_forward_mods_dev(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev);
+
+/* Modulator.forward + SirenNet.forward (modulated_siren.py:325-343): latent (B,Z) -> out (B,S,S).
+ * If mods_out is non-NULL the (L,B,H) modulations are returned as well. */
+MSIREN_API int msiren_forward_latent(msiren_handle h, const float* z_host, int64_t B, float* out_host, float* mods_out_host);
+MSIREN_API int msiren_forward_latent_dev(msiren_handle h, const float* z_dev, int64_t B, float* out_dev, float* mods_out_dev);
+
+/* ModulatedSiren.forward (modulated_siren.py:435-457), custom-encoder branch
+ * (siren_encoder.py:503-512,565-577): tiles (B,O,O) -> out (B,S,S). */
+MSIREN_API int msiren_forward_tiles(msiren_handle h, const float* tiles_host, int64_t B, float* out_host);
+MSIREN_API int msiren_forward_tiles_dev(msiren_handle h, const float* tiles_dev, int64_t B, float* out_dev);
+
+/* The slice pipeline around the model call as metrics_error drives it (src/util/error.py:231-249):
+ * image (Hh,Ww) -> image_to_patches(O,I) (tiling.py:10-64) -> black-patch filter (mean < 1e-10,
+ * tiling.py:184-198,244-271) -> ModulatedSiren.forward on the non-black tiles -> zeros re-inserted
+ * (tiling.py:274-303) -> weighted overlap-add (tiling.py:67-140) -> recon (nV*I, nH*I).
+ * n_slices images of identical size are processed as one batch.  recon_rows/cols may be NULL. */
+MSIREN_API int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int64_t n_slices, int32_t height,
+                                  int32_t width, float* recon_dev);
+MSIREN_API int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t n_slices, int32_t height,
+                              int32_t width, float* recon_host);
+/* Output geometry of the above: nV = ceil(height/I), nH = ceil(width/I); recon is (nV*I, nH*I). */
+MSIREN_API int msiren_recon_shape(msiren_handle h, int32_t height, int32_t width, int32_t* n_vertical, int32_t* n_horizontal);
+
+/* Stand-alone tiling steps on device buffers (same references as above). */
+MSIREN_API int msiren_image_to_patches_dev(msiren_handle h, const float* images_dev, int64_t n_slices, int32_t height,
+                                int32_t width, float* patches_dev /* (n*nV*nH, O, O) */);
+MSIREN_API int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev /* (n*nV*nH, S, S) */, int64_t n_slices,
+                             int32_t n_vertical, int32_t n_horizontal, float* recon_dev);
+
+/* Blocks until everything enqueued on the handle's stream has finished (the reference's implicit
+ * synchronisation at .cpu(), error.py:256-258). */
+MSIREN_API int msiren_sync(msiren_handle h);
+
+/* ---- device memory + timing helpers (so that a host needs no other GPU runtime) --------------- */
+
+MSIREN_API int msiren_dev_alloc(msiren_handle h, size_t bytes, void** dev_ptr);
+MSIREN_API int msiren_dev_free(msiren_handle h, void* dev_ptr);
+MSIREN_API int msiren_memcpy_h2d(msiren_handle h, void* dst_dev, const void* src_host, size_t bytes);
+MSIREN_API int msiren_memcpy_d2h(msiren_handle h, void* dst_host, const void* src_dev, size_t bytes);
+
+/* HIP events on the handle's stream: start .. stop brackets the launches enqueued in between;
+ * stop synchronises and returns elapsed milliseconds. */
+MSIREN_API int msiren_timer_start(msiren_handle h);
+MSIREN_API int msiren_timer_stop(msiren_handle h, float* elapsed_ms);
+/* Per-kernel accounting: while enabled, every launch of the fused trunk kernel is bracketed by its
+ * own event pair; msiren_profile_read returns launch count and summed milliseconds since enable. */
+MSIREN_API int msiren_profile_enable(msiren_handle h, int32_t on);
+MSIREN_API int msiren_profile_read(msiren_handle h, int64_t* launches, double* trunk_ms_total);
+
+/* name (<=255 chars + NUL), compute units, clock in MHz, total HBM bytes of the handle's device. */
+MSIREN_API int msiren_device_info(msiren_handle h, char* name256, int32_t* compute_units, int32_t* clock_mhz,
+                       uint64_t* hbm_bytes);
+MSIREN_API int msiren_device_count(int32_t* count);
+/* Algorithmic FLOPs per coordinate for the handle's configuration: 2*2*H + (L-1)*2*H*H + 2*H. */
+MSIREN_API int msiren_flops_per_coord(msiren_handle h, double* flops);
+MSIREN_API int msiren_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSIREN_H */

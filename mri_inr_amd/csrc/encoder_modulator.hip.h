@@ -1,0 +1,158 @@
+// Producers of the modulation vectors: FixedEncoder (tile -> latent) and Modulator (latent -> mods).
+//
+// Reference: src/networks/encoding/siren_encoder.py:503-512,565-577 (three convolutions with
+// LeakyReLU(0.2) + Linear(64, Z)) and src/networks/modulated_siren.py:325-343 (L x Linear+ReLU with
+// the latent re-concatenated, hidden first).  Together they are 2.1 MFLOP per patch against the
+// trunk's 303 MFLOP, so these are plain fp32 VALU kernels organised for coalesced weight reads and
+// LDS-resident activations, not MFMA kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace msiren {
+
+struct EncoderParams {
+    const float* c1w;  // (16, 9)              conv 3x3 s2 p1, 1 -> 16
+    const float* c1b;  // (16)
+    const float* c2w;  // (144, 32) transposed conv 3x3 s2 p1, 16 -> 32; k = c*9 + ky*3 + kx
+    const float* c2b;  // (32)
+    const float* c3w;  // (2048, 64) transposed conv 8x8, 32 -> 64;      k = c*64 + y*8 + x
+    const float* c3b;  // (64)
+    const float* fcw;  // (64, Z) transposed   Linear(64, Z)
+    const float* fcb;  // (Z)
+    int Z;
+};
+
+__device__ __forceinline__ float leaky02(float x) { return x >= 0.f ? x : 0.2f * x; }
+
+// One workgroup (256 threads) per 32x32 tile; all intermediate feature maps live in LDS.
+__global__ __launch_bounds__(256) void encoder_kernel(EncoderParams p, const float* __restrict__ tiles, float* __restrict__ latent) {
+    __shared__ float t0[33 * 33];       // input with a zero row/column in front (padding = 1)
+    __shared__ float a1[16 * 17 * 17];  // conv1 output, same front padding for conv2
+    __shared__ float a2[2048];          // conv2 output, flattened (c, y, x)
+    __shared__ float red[4 * 64];
+    __shared__ float a3[64];
+    const int tid = threadIdx.x;
+    const float* tile = tiles + (size_t)blockIdx.x * 1024;
+
+    for (int i = tid; i < 33 * 33; i += 256) {
+        const int y = i / 33, x = i - y * 33;
+        t0[i] = (y == 0 || x == 0) ? 0.f : tile[(y - 1) * 32 + (x - 1)];
+    }
+    for (int i = tid; i < 16 * 17 * 17; i += 256) {
+        const int r = i % (17 * 17);
+        if (r < 17 || r % 17 == 0) a1[i] = 0.f;
+    }
+    __syncthreads();
+
+    // conv1: 16 x 16 x 16 outputs, 9 MACs each
+    for (int i = tid; i < 16 * 256; i += 256) {
+        const int c = i >> 8, y = (i >> 4) & 15, x = i & 15;
+        float s = p.c1b[c];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) s = __builtin_fmaf(t0[(2 * y + ky) * 33 + 2 * x + kx], p.c1w[c * 9 + ky * 3 + kx], s);
+        a1[c * 289 + (y + 1) * 17 + (x + 1)] = leaky02(s);
+    }
+    __syncthreads();
+
+    // conv2: 32 x 8 x 8 outputs, 144 MACs each; thread = (output channel, output row)
+    {
+        const int o = tid & 31, y = tid >> 5;
+        float s[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) s[x] = p.c2b[o];
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float w = p.c2w[(c * 9 + ky * 3 + kx) * 32 + o];
+                    const float* row = &a1[c * 289 + (2 * y + ky) * 17 + kx];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) s[x] = __builtin_fmaf(row[2 * x], w, s[x]);
+                }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) a2[o * 64 + y * 8 + x] = leaky02(s[x]);
+    }
+    __syncthreads();
+
+    // conv3 == Linear(2048, 64): 4 k-slices x 64 outputs, reduced through LDS
+    {
+        const int o = tid & 63, ks = tid >> 6;
+        float s = 0.f;
+        const float* w = p.c3w + (size_t)(ks * 512) * 64 + o;
+        const float* a = a2 + ks * 512;
+#pragma unroll 8
+        for (int k = 0; k < 512; ++k) s = __builtin_fmaf(a[k], w[(size_t)k * 64], s);
+        red[ks * 64 + o] = s;
+    }
+    __syncthreads();
+    if (tid < 64) a3[tid] = leaky02(red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid] + p.c3b[tid]);
+    __syncthreads();
+
+    // Linear(64, Z)
+    for (int z = tid; z < p.Z; z += 256) {
+        float s = p.fcb[z];
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) s = __builtin_fmaf(a3[k], p.fcw[k * p.Z + z], s);
+        latent[(size_t)blockIdx.x * p.Z + z] = s;
+    }
+}
+
+// ---- modulator ----------------------------------------------------------------------------------
+constexpr int MOD_ROWS = 8;  // patches per workgroup
+
+struct ModulatorLayerParams {
+    const float* wt;     // (Kh + Z, H): transposed nn.Linear weight, rows ordered [hidden ; latent]
+    const float* bias;   // (H)
+    const float* hprev;  // (B, H) previous layer's output, or nullptr for layer 0
+    const float* z;      // (B, Z)
+    float* out;          // (B, H)
+    int B, H, Z, Kh;
+};
+
+// out[b, f] = relu(bias[f] + sum_k in[b, k] * wt[k, f]),  in = [hprev[b] ; z[b]].
+// grid = (ceil(B / MOD_ROWS), ceil(H / 64)); 256 threads = 64 features x 4 k-slices.
+__global__ __launch_bounds__(256) void modulator_layer_kernel(ModulatorLayerParams p) {
+    extern __shared__ __attribute__((aligned(16))) float in[];  // [MOD_ROWS][K]
+    __shared__ float red[4][MOD_ROWS][64];
+    const int tid = threadIdx.x;
+    const int K = p.Kh + p.Z;
+    const int b0 = blockIdx.x * MOD_ROWS;
+    for (int i = tid; i < MOD_ROWS * K; i += 256) {
+        const int r = i / K, k = i - r * K;
+        const int b = b0 + r;
+        float v = 0.f;
+        if (b < p.B) v = k < p.Kh ? p.hprev[(size_t)b * p.H + k] : p.z[(size_t)b * p.Z + (k - p.Kh)];
+        in[i] = v;
+    }
+    __syncthreads();
+    const int fi = tid & 63, ks = tid >> 6;
+    const int f = blockIdx.y * 64 + fi;
+    const int kper = (K + 3) / 4;
+    const int k0 = ks * kper, k1 = min(K, k0 + kper);
+    float acc[MOD_ROWS];
+#pragma unroll
+    for (int r = 0; r < MOD_ROWS; ++r) acc[r] = 0.f;
+    if (f < p.H) {
+        for (int k = k0; k < k1; ++k) {
+            const float w = p.wt[(size_t)k * p.H + f];
+#pragma unroll
+            for (int r = 0; r < MOD_ROWS; ++r) acc[r] = __builtin_fmaf(in[r * K + k], w, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MOD_ROWS; ++r) red[ks][r][fi] = acc[r];
+    __syncthreads();
+    for (int i = tid; i < MOD_ROWS * 64; i += 256) {
+        const int r = i >> 6, ff = i & 63;
+        const int b = b0 + r, fo = blockIdx.y * 64 + ff;
+        if (b < p.B && fo < p.H) {
+            const float s = red[0][r][ff] + red[1][r][ff] + red[2][r][ff] + red[3][r][ff] + p.bias[fo];
+            p.out[(size_t)b * p.H + fo] = s > 0.f ? s : 0.f;
+        }
+    }
+}
+
+}  // namespace msiren

@@ -1,0 +1,827 @@
+// libmsiren.so -- host side of the C ABI declared in include/msiren.h.
+//
+// Owns: the device context (one device, one stream), the weight store keyed by the reference's
+// state_dict names, the host-side packing of weights into kernel layouts, grow-only device
+// workspaces, and the launch sequence
+//     [tiling] -> encoder -> modulator -> fused SIREN trunk -> [weighted fold]
+// Nothing here falls back to the CPU: every forward entry point launches HIP kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/msiren.h"
+#include "encoder_modulator.hip.h"
+#include "siren_trunk_f32.hip.h"
+#include "tiling.hip.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(MSIREN_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct msiren_ctx {
+    msiren_config cfg{};
+    int H = 0, HP = 0, L = 0, Z = 0, S = 0, P = 0, O = 0, I = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::string, std::vector<float>> tensors;  // state_dict, host copies
+    std::map<std::string, size_t> expected;             // key -> element count
+    bool committed = false, have_modulator = false, have_encoder = false;
+    // trunk
+    float *d_grid = nullptr, *d_l0 = nullptr, *d_wp = nullptr, *d_bias = nullptr, *d_wout = nullptr;
+    float bout = 0.f, cg0 = 0.f, cg = 0.f;
+    // modulator: transposed weights so that consecutive threads read consecutive outputs
+    float *d_modw = nullptr, *d_modb = nullptr;
+    // encoder
+    float *d_encw = nullptr;
+    msiren::EncoderParams enc{};
+    float* d_foldw = nullptr;  // (S,S) overlap-add weights
+    // workspaces
+    DevBuf ws_mods, ws_modpad, ws_out, ws_latent, ws_tiles, ws_in, ws_patches, ws_keep, ws_rec, ws_img;
+    // profiling
+    bool profile = false;
+    int64_t prof_launches = 0;
+    double prof_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+};
+
+namespace {
+
+int use_device(msiren_ctx* h) {
+    HIPCHK(hipSetDevice(h->cfg.device));
+    return 0;
+}
+
+int ensure(msiren_ctx* h, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t cap = bytes + bytes / 4 + 256;
+    HIPCHK(hipMalloc(&b.p, cap));
+    b.cap = cap;
+    (void)h;
+    return 0;
+}
+
+int upload(float** dst, const std::vector<float>& src) {
+    if (*dst) HIPCHK(hipFree(*dst));
+    *dst = nullptr;
+    HIPCHK(hipMalloc((void**)dst, src.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void declare_expected(msiren_ctx* h) {
+    auto& e = h->expected;
+    const size_t H = h->H, Z = h->Z, L = h->L;
+    e["grid"] = (size_t)h->P * 2;
+    for (size_t l = 0; l < L; ++l) {
+        const std::string p = "net.layers." + std::to_string(l);
+        e[p + ".weight"] = H * (l == 0 ? 2 : H);
+        if (h->cfg.use_bias) e[p + ".bias"] = H;
+        const std::string m = "modulator.layers." + std::to_string(l) + ".0";
+        e[m + ".weight"] = H * (l == 0 ? Z : H + Z);
+        e[m + ".bias"] = H;
+    }
+    e["net.last_layer.weight"] = H;
+    if (h->cfg.use_bias) e["net.last_layer.bias"] = 1;
+    const std::string en = "encoder.encoder.encoder.";
+    e[en + "0.weight"] = 16 * 1 * 3 * 3;
+    e[en + "0.bias"] = 16;
+    e[en + "2.weight"] = 32 * 16 * 3 * 3;
+    e[en + "2.bias"] = 32;
+    e[en + "4.weight"] = 64 * 32 * 8 * 8;
+    e[en + "4.bias"] = 64;
+    e[en + "7.weight"] = Z * 64;
+    e[en + "7.bias"] = Z;
+}
+
+const std::vector<float>* get(msiren_ctx* h, const std::string& k) {
+    auto it = h->tensors.find(k);
+    return it == h->tensors.end() ? nullptr : &it->second;
+}
+
+// ---- trunk packing --------------------------------------------------------------------------
+// Everything is scaled by w0/(2*pi) in double before rounding to fp32, so that the kernel's
+// accumulator is the sine argument in revolutions (see siren_trunk_f32.hip.h).
+int pack_trunk(msiren_ctx* h) {
+    const int H = h->H, HP = h->HP, L = h->L;
+    const int TT = HP / 128, QN = HP / 8;
+    const double two_pi = 6.283185307179586476925286766559;
+    const double c0 = (double)h->cfg.w0_initial / two_pi, c = (double)h->cfg.w0 / two_pi;
+    std::string missing;
+    auto need = [&](const std::string& k) -> const std::vector<float>* {
+        const auto* v = get(h, k);
+        if (!v) missing += (missing.empty() ? "" : ", ") + k;
+        return v;
+    };
+    std::vector<const std::vector<float>*> W(L), Bv(L);
+    for (int l = 0; l < L; ++l) {
+        W[l] = need("net.layers." + std::to_string(l) + ".weight");
+        Bv[l] = h->cfg.use_bias ? need("net.layers." + std::to_string(l) + ".bias") : nullptr;
+    }
+    const auto* Wo = need("net.last_layer.weight");
+    const auto* Bo = h->cfg.use_bias ? need("net.last_layer.bias") : nullptr;
+    if (!missing.empty())
+        return fail(MSIREN_E_STATE, "Missing key(s) in state_dict: %s", missing.c_str());
+
+    std::vector<float> grid;
+    if (const auto* g = get(h, "grid")) {
+        grid = *g;
+    } else {  // the reference registers it as a buffer; rebuild it if a checkpoint lacks it
+        grid.resize((size_t)h->P * 2);
+        const int S = h->S;
+        std::vector<float> lin(S);
+        const float step = S > 1 ? (1.0f - (-1.0f)) / (float)(S - 1) : 0.f;
+        for (int i = 0; i < S; ++i) lin[i] = (i < S / 2) ? (-1.0f + step * (float)i) : (1.0f - step * (float)(S - 1 - i));
+        for (int a = 0; a < S; ++a)
+            for (int b2 = 0; b2 < S; ++b2) {
+                grid[((size_t)a * S + b2) * 2 + 0] = lin[a];
+                grid[((size_t)a * S + b2) * 2 + 1] = lin[b2];
+            }
+    }
+
+    std::vector<float> l0((size_t)HP * 4, 0.f);
+    for (int f = 0; f < H; ++f) {
+        l0[(size_t)f * 4 + 0] = (float)((double)(*W[0])[(size_t)f * 2 + 0] * c0);
+        l0[(size_t)f * 4 + 1] = (float)((double)(*W[0])[(size_t)f * 2 + 1] * c0);
+        l0[(size_t)f * 4 + 2] = Bv[0] ? (float)((double)(*Bv[0])[f] * c0) : 0.f;
+    }
+    const int nh = L > 1 ? L - 1 : 0;
+    std::vector<float> wp((size_t)std::max(nh, 1) * 4 * QN * TT * 256, 0.f);
+    std::vector<float> bias((size_t)std::max(nh, 1) * HP, 0.f);
+    for (int l = 1; l < L; ++l) {
+        const std::vector<float>& w = *W[l];
+        for (int wave = 0; wave < 4; ++wave)
+            for (int q = 0; q < QN; ++q)
+                for (int tt = 0; tt < TT; ++tt)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int f = wave * 32 * TT + 32 * tt + (lane & 31);
+                        float* dst = &wp[(((((size_t)(l - 1) * 4 + wave) * QN + q) * TT + tt) * 64 + lane) * 4];
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = 8 * q + 4 * (lane >> 5) + j;
+                            dst[j] = (f < H && k < H) ? (float)((double)w[(size_t)f * H + k] * c) : 0.f;
+                        }
+                    }
+        if (Bv[l])
+            for (int f = 0; f < H; ++f) bias[(size_t)(l - 1) * HP + f] = (float)((double)(*Bv[l])[f] * c);
+    }
+    std::vector<float> wout(HP, 0.f);
+    for (int f = 0; f < H; ++f) wout[f] = (float)((double)(*Wo)[f] * c);
+    h->bout = Bo ? (float)((double)(*Bo)[0] * c) : 0.f;
+    // Morlet: exp(-0.5 p^2) with p = r * 2pi / w  ->  exp2(cg * r^2)
+    const double log2e = 1.4426950408889634;
+    h->cg0 = (float)(-0.5 * log2e * (two_pi / h->cfg.w0_initial) * (two_pi / h->cfg.w0_initial));
+    h->cg = (float)(-0.5 * log2e * (two_pi / h->cfg.w0) * (two_pi / h->cfg.w0));
+
+    int rc;
+    if ((rc = upload(&h->d_grid, grid))) return rc;
+    if ((rc = upload(&h->d_l0, l0))) return rc;
+    if ((rc = upload(&h->d_wp, wp))) return rc;
+    if ((rc = upload(&h->d_bias, bias))) return rc;
+    if ((rc = upload(&h->d_wout, wout))) return rc;
+    return 0;
+}
+
+// ---- modulator / encoder packing ------------------------------------------------------------
+int pack_modulator(msiren_ctx* h) {
+    const int H = h->H, Z = h->Z, L = h->L;
+    // transposed: Wt[l][k][f], k over [hidden(H) ; latent(Z)] (layer 0: latent only), so that a
+    // thread per output feature reads consecutive addresses
+    size_t total = 0;
+    for (int l = 0; l < L; ++l) total += (size_t)(l == 0 ? Z : H + Z) * H;
+    std::vector<float> wt(total), bb((size_t)L * H);
+    size_t off = 0;
+    for (int l = 0; l < L; ++l) {
+        const auto* w = get(h, "modulator.layers." + std::to_string(l) + ".0.weight");
+        const auto* b = get(h, "modulator.layers." + std::to_string(l) + ".0.bias");
+        if (!w || !b) return 1;  // not present: latent/tiles entry points stay unavailable
+        const int K = (l == 0 ? Z : H + Z);
+        for (int f = 0; f < H; ++f)
+            for (int k = 0; k < K; ++k) wt[off + (size_t)k * H + f] = (*w)[(size_t)f * K + k];
+        for (int f = 0; f < H; ++f) bb[(size_t)l * H + f] = (*b)[f];
+        off += (size_t)K * H;
+    }
+    int rc;
+    if ((rc = upload(&h->d_modw, wt))) return rc;
+    if ((rc = upload(&h->d_modb, bb))) return rc;
+    return 0;
+}
+
+int pack_encoder(msiren_ctx* h) {
+    const std::string en = "encoder.encoder.encoder.";
+    const char* keys[8] = {"0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias", "7.weight", "7.bias"};
+    const std::vector<float>* t[8];
+    for (int i = 0; i < 8; ++i) {
+        t[i] = get(h, en + keys[i]);
+        if (!t[i]) return 1;
+    }
+    const int Z = h->Z;
+    // one blob: [c1w 16x9][c1b 16][c2w (144,32) transposed][c2b 32][c3w (2048,64) transposed][c3b 64]
+    //           [fcw (64,Z) transposed][fcb Z]
+    std::vector<float> blob;
+    auto push = [&](const std::vector<float>& v) {
+        size_t o = blob.size();
+        blob.insert(blob.end(), v.begin(), v.end());
+        while (blob.size() % 4) blob.push_back(0.f);
+        return o;
+    };
+    msiren::EncoderParams ep{};
+    size_t o_c1w = push(*t[0]);
+    size_t o_c1b = push(*t[1]);
+    std::vector<float> c2t((size_t)144 * 32);
+    for (int o = 0; o < 32; ++o)
+        for (int k = 0; k < 144; ++k) c2t[(size_t)k * 32 + o] = (*t[2])[(size_t)o * 144 + k];
+    size_t o_c2w = push(c2t);
+    size_t o_c2b = push(*t[3]);
+    std::vector<float> c3t((size_t)2048 * 64);
+    for (int o = 0; o < 64; ++o)
+        for (int k = 0; k < 2048; ++k) c3t[(size_t)k * 64 + o] = (*t[4])[(size_t)o * 2048 + k];
+    size_t o_c3w = push(c3t);
+    size_t o_c3b = push(*t[5]);
+    std::vector<float> fct((size_t)64 * Z);
+    for (int o = 0; o < Z; ++o)
+        for (int k = 0; k < 64; ++k) fct[(size_t)k * Z + o] = (*t[6])[(size_t)o * 64 + k];
+    size_t o_fcw = push(fct);
+    size_t o_fcb = push(*t[7]);
+    int rc;
+    if ((rc = upload(&h->d_encw, blob))) return rc;
+    ep.c1w = h->d_encw + o_c1w;
+    ep.c1b = h->d_encw + o_c1b;
+    ep.c2w = h->d_encw + o_c2w;
+    ep.c2b = h->d_encw + o_c2b;
+    ep.c3w = h->d_encw + o_c3w;
+    ep.c3b = h->d_encw + o_c3b;
+    ep.fcw = h->d_encw + o_fcw;
+    ep.fcb = h->d_encw + o_fcb;
+    ep.Z = Z;
+    h->enc = ep;
+    return 0;
+}
+
+int pack_fold_weights(msiren_ctx* h) {
+    // w[i][j] = exp(-0.1 * dist((i,j), centre)) / max   (src/util/tiling.py:67-88; fp64 maths
+    // rounded to fp32 element-wise, then divided by the fp32 maximum, as the reference does)
+    const int S = h->S;
+    std::vector<float> w((size_t)S * S);
+    const double c = (S - 1) / 2.0;
+    float mx = 0.f;
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < S; ++j) {
+            const double d = std::sqrt((i - c) * (i - c) + (j - c) * (j - c));
+            w[(size_t)i * S + j] = (float)std::exp(-0.1 * d);
+            mx = std::max(mx, w[(size_t)i * S + j]);
+        }
+    for (auto& v : w) v = v / mx;
+    return upload(&h->d_foldw, w);
+}
+
+// ---- launches ---------------------------------------------------------------------------------
+template <int HP>
+int launch_trunk_hp(msiren_ctx* h, const msiren::TrunkParams& p, int grid) {
+    const size_t lds = (size_t)HP * 256;
+    const int act = h->cfg.activation, res = h->cfg.residual;
+#define MSIREN_LAUNCH(A, R)                                                                        \
+    do {                                                                                           \
+        auto k = msiren::siren_trunk_f32_kernel<HP, A, R>;                                         \
+        if (lds > 64 * 1024)                                                                       \
+            HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->stream, p);                           \
+    } while (0)
+    if (act == MSIREN_ACT_MORLET) {
+        if (res) MSIREN_LAUNCH(1, 1); else MSIREN_LAUNCH(1, 0);
+    } else {
+        if (res) MSIREN_LAUNCH(0, 1); else MSIREN_LAUNCH(0, 0);
+    }
+#undef MSIREN_LAUNCH
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
+    if (B == 0) return 0;
+    const int chunks = (h->P + 63) / 64;
+    if (B * (int64_t)chunks > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
+    const float* mods = mods_dev;
+    int stride = h->H;
+    if (h->HP != h->H) {  // zero-pad the feature axis once so the kernel can use float4 loads
+        int rc = ensure(h, h->ws_modpad, (size_t)h->L * B * h->HP * sizeof(float));
+        if (rc) return rc;
+        const int64_t n = (int64_t)h->L * B * h->HP;
+        hipLaunchKernelGGL(msiren::pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
+                           mods_dev, (float*)h->ws_modpad.p, (int64_t)h->L * B, h->H, h->HP);
+        HIPCHK(hipGetLastError());
+        mods = (const float*)h->ws_modpad.p;
+        stride = h->HP;
+    }
+    msiren::TrunkParams p{};
+    p.grid = h->d_grid;
+    p.l0 = h->d_l0;
+    p.wp = h->d_wp;
+    p.bias = h->d_bias;
+    p.wout = h->d_wout;
+    p.mods = mods;
+    p.out = out_dev;
+    p.bout = h->bout;
+    p.cg0 = h->cg0;
+    p.cg = h->cg;
+    p.B = (int)B;
+    p.P = h->P;
+    p.L = h->L;
+    p.mod_stride = stride;
+    p.chunks = chunks;
+    const int grid = (int)(B * chunks);
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profile) {
+        if (h->prof_used == h->prof_events.size()) {
+            hipEvent_t a, b2;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b2));
+            h->prof_events.emplace_back(a, b2);
+        }
+        e0 = h->prof_events[h->prof_used].first;
+        e1 = h->prof_events[h->prof_used].second;
+        h->prof_used++;
+        HIPCHK(hipEventRecord(e0, h->stream));
+    }
+    int rc;
+    switch (h->HP) {
+        case 128: rc = launch_trunk_hp<128>(h, p, grid); break;
+        case 256: rc = launch_trunk_hp<256>(h, p, grid); break;
+        case 384: rc = launch_trunk_hp<384>(h, p, grid); break;
+        case 512: rc = launch_trunk_hp<512>(h, p, grid); break;
+        default: return fail(MSIREN_E_INVALID, "dim_hidden=%d (padded %d) is not supported by the fp32 trunk (max 512)", h->H, h->HP);
+    }
+    if (rc) return rc;
+    if (h->profile) HIPCHK(hipEventRecord(e1, h->stream));
+    return 0;
+}
+
+int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_dev) {
+    if (B == 0) return 0;
+    if (!h->have_modulator) return fail(MSIREN_E_STATE, "modulator.* weights were not loaded");
+    size_t off = 0;
+    for (int l = 0; l < h->L; ++l) {
+        const int Kh = (l == 0 ? 0 : h->H);
+        msiren::ModulatorLayerParams mp{};
+        mp.wt = h->d_modw + off;
+        mp.bias = h->d_modb + (size_t)l * h->H;
+        mp.hprev = l == 0 ? nullptr : mods_dev + (size_t)(l - 1) * B * h->H;
+        mp.z = z_dev;
+        mp.out = mods_dev + (size_t)l * B * h->H;
+        mp.B = (int)B;
+        mp.H = h->H;
+        mp.Z = h->Z;
+        mp.Kh = Kh;
+        dim3 grid((unsigned)((B + msiren::MOD_ROWS - 1) / msiren::MOD_ROWS), (unsigned)((h->H + 63) / 64));
+        const size_t lds = (size_t)msiren::MOD_ROWS * (Kh + h->Z) * sizeof(float);
+        hipLaunchKernelGGL(msiren::modulator_layer_kernel, grid, dim3(256), lds, h->stream, mp);
+        HIPCHK(hipGetLastError());
+        off += (size_t)(Kh + h->Z) * h->H;
+    }
+    return 0;
+}
+
+int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_dev) {
+    if (B == 0) return 0;
+    if (!h->have_encoder) return fail(MSIREN_E_STATE, "encoder.* weights were not loaded");
+    hipLaunchKernelGGL(msiren::encoder_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, h->enc, tiles_dev, z_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int forward_latent_dev(msiren_ctx* h, const float* z_dev, int64_t B, float* out_dev, float* mods_out_dev) {
+    float* mods = mods_out_dev;
+    if (!mods) {
+        int rc = ensure(h, h->ws_mods, (size_t)h->L * B * h->H * sizeof(float));
+        if (rc) return rc;
+        mods = (float*)h->ws_mods.p;
+    }
+    int rc = launch_modulator(h, z_dev, B, mods);
+    if (rc) return rc;
+    return launch_trunk(h, mods, B, out_dev);
+}
+
+int forward_tiles_dev(msiren_ctx* h, const float* tiles_dev, int64_t B, float* out_dev) {
+    int rc = ensure(h, h->ws_latent, (size_t)B * h->Z * sizeof(float));
+    if (rc) return rc;
+    rc = launch_encoder(h, tiles_dev, B, (float*)h->ws_latent.p);
+    if (rc) return rc;
+    return forward_latent_dev(h, (const float*)h->ws_latent.p, B, out_dev, nullptr);
+}
+
+int check(msiren_ctx* h, bool need_commit = true) {
+    if (!h) return fail(MSIREN_E_INVALID, "null handle");
+    if (need_commit && !h->committed) return fail(MSIREN_E_STATE, "weights not committed: call msiren_set_tensor for every net.* key, then msiren_commit_weights");
+    return use_device(h);
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int msiren_abi_version(void) { return MSIREN_ABI_VERSION; }
+
+const char* msiren_last_error(void) { return g_err.c_str(); }
+
+int msiren_device_count(int32_t* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    if (count) *count = n;
+    return 0;
+}
+
+int msiren_create(const msiren_config* cfg, msiren_handle* out) {
+    if (!cfg || !out) return fail(MSIREN_E_INVALID, "null argument");
+    if (cfg->abi_version != MSIREN_ABI_VERSION)
+        return fail(MSIREN_E_INVALID, "ABI version mismatch: header %d, library %d", cfg->abi_version, MSIREN_ABI_VERSION);
+    if (cfg->dim_in != 2) return fail(MSIREN_E_INVALID, "dim_in must be 2 (the coordinate grid is a 2-D meshgrid), got %d", cfg->dim_in);
+    if (cfg->dim_out != 1) return fail(MSIREN_E_INVALID, "dim_out must be 1 (the reference's squeeze(2)+rearrange only works for 1), got %d", cfg->dim_out);
+    if (cfg->dim_hidden < 1 || cfg->dim_hidden > 512) return fail(MSIREN_E_INVALID, "dim_hidden must be in [1,512], got %d", cfg->dim_hidden);
+    if (cfg->num_layers < 1 || cfg->num_layers > 64) return fail(MSIREN_E_INVALID, "num_layers must be in [1,64], got %d", cfg->num_layers);
+    if (cfg->latent_dim < 1) return fail(MSIREN_E_INVALID, "latent_dim must be positive, got %d", cfg->latent_dim);
+    if (cfg->siren_patch_size < 2) return fail(MSIREN_E_INVALID, "siren_patch_size must be >= 2, got %d", cfg->siren_patch_size);
+    if (cfg->inner_patch_size < 1 || cfg->outer_patch_size < cfg->inner_patch_size)
+        return fail(MSIREN_E_INVALID, "need outer_patch_size >= inner_patch_size >= 1");
+    if (cfg->activation != MSIREN_ACT_SINE && cfg->activation != MSIREN_ACT_MORLET) return fail(MSIREN_E_INVALID, "unknown activation %d", cfg->activation);
+    if (cfg->precision != MSIREN_PREC_F32) return fail(MSIREN_E_INVALID, "precision %d is not available in this build (fp32 only)", cfg->precision);
+    if (cfg->w0 == 0.f || cfg->w0_initial == 0.f) return fail(MSIREN_E_INVALID, "w0 and w0_initial must be non-zero");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(MSIREN_E_INVALID, "device %d out of range (%d visible)", cfg->device, ndev);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MSIREN_E_INVALID, "device %d is %s; libmsiren is built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
+    auto* h = new msiren_ctx();
+    h->cfg = *cfg;
+    h->H = cfg->dim_hidden;
+    h->HP = (cfg->dim_hidden + 127) / 128 * 128;
+    h->L = cfg->num_layers;
+    h->Z = cfg->latent_dim;
+    h->S = cfg->siren_patch_size;
+    h->P = h->S * h->S;
+    h->O = cfg->outer_patch_size;
+    h->I = cfg->inner_patch_size;
+    declare_expected(h);
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(MSIREN_E_HIP, "context creation failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return 0;
+}
+
+int msiren_destroy(msiren_handle h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    float* ptrs[] = {h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modb, h->d_encw, h->d_foldw};
+    for (float* p : ptrs)
+        if (p) (void)hipFree(p);
+    DevBuf* bufs[] = {&h->ws_mods, &h->ws_modpad, &h->ws_out, &h->ws_latent, &h->ws_tiles, &h->ws_in, &h->ws_patches, &h->ws_keep, &h->ws_rec, &h->ws_img};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto& pr : h->prof_events) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int msiren_set_tensor(msiren_handle h, const char* name, const float* host_data, size_t n) {
+    if (!h || !name || (!host_data && n)) return fail(MSIREN_E_INVALID, "null argument");
+    auto it = h->expected.find(name);
+    if (it == h->expected.end()) return fail(MSIREN_E_INVALID, "Unexpected key in state_dict: \"%s\"", name);
+    if (it->second != n)
+        return fail(MSIREN_E_SHAPE, "size mismatch for %s: got %zu elements, the configuration implies %zu", name, n, it->second);
+    h->tensors[name].assign(host_data, host_data + n);
+    h->committed = false;
+    return 0;
+}
+
+int msiren_commit_weights(msiren_handle h) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = pack_trunk(h))) return rc;
+    if ((rc = pack_fold_weights(h))) return rc;
+    rc = pack_modulator(h);
+    if (rc < 0) return rc;
+    h->have_modulator = (rc == 0);
+    rc = pack_encoder(h);
+    if (rc < 0) return rc;
+    h->have_encoder = (rc == 0);
+    h->committed = true;
+    return 0;
+}
+
+int msiren_forward_mods_dev(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!mods_dev || !out_dev))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
+    return launch_trunk(h, mods_dev, B, out_dev);
+}
+
+int msiren_forward_mods(msiren_handle h, const float* mods_host, int64_t B, float* out_host) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!mods_host || !out_host))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
+    if (B == 0) return 0;
+    const size_t nm = (size_t)h->L * B * h->H * sizeof(float), no = (size_t)B * h->P * sizeof(float);
+    if ((rc = ensure(h, h->ws_mods, nm)) || (rc = ensure(h, h->ws_out, no))) return rc;
+    HIPCHK(hipMemcpyAsync(h->ws_mods.p, mods_host, nm, hipMemcpyHostToDevice, h->stream));
+    if ((rc = launch_trunk(h, (const float*)h->ws_mods.p, B, (float*)h->ws_out.p))) return rc;
+    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int msiren_forward_latent_dev(msiren_handle h, const float* z_dev, int64_t B, float* out_dev, float* mods_out_dev) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!z_dev || !out_dev))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
+    return forward_latent_dev(h, z_dev, B, out_dev, mods_out_dev);
+}
+
+int msiren_forward_latent(msiren_handle h, const float* z_host, int64_t B, float* out_host, float* mods_out_host) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!z_host || !out_host))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
+    if (B == 0) return 0;
+    const size_t nz = (size_t)B * h->Z * sizeof(float), no = (size_t)B * h->P * sizeof(float);
+    const size_t nm = (size_t)h->L * B * h->H * sizeof(float);
+    if ((rc = ensure(h, h->ws_latent, nz)) || (rc = ensure(h, h->ws_out, no)) || (rc = ensure(h, h->ws_mods, nm))) return rc;
+    HIPCHK(hipMemcpyAsync(h->ws_latent.p, z_host, nz, hipMemcpyHostToDevice, h->stream));
+    if ((rc = forward_latent_dev(h, (const float*)h->ws_latent.p, B, (float*)h->ws_out.p, (float*)h->ws_mods.p))) return rc;
+    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->stream));
+    if (mods_out_host) HIPCHK(hipMemcpyAsync(mods_out_host, h->ws_mods.p, nm, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int msiren_forward_tiles_dev(msiren_handle h, const float* tiles_dev, int64_t B, float* out_dev) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!tiles_dev || !out_dev))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
+    if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles (siren_encoder.py:499), outer_patch_size=%d", h->O);
+    return forward_tiles_dev(h, tiles_dev, B, out_dev);
+}
+
+int msiren_forward_tiles(msiren_handle h, const float* tiles_host, int64_t B, float* out_host) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!tiles_host || !out_host))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
+    if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles (siren_encoder.py:499), outer_patch_size=%d", h->O);
+    if (B == 0) return 0;
+    const size_t nt = (size_t)B * h->O * h->O * sizeof(float), no = (size_t)B * h->P * sizeof(float);
+    if ((rc = ensure(h, h->ws_tiles, nt)) || (rc = ensure(h, h->ws_out, no))) return rc;
+    HIPCHK(hipMemcpyAsync(h->ws_tiles.p, tiles_host, nt, hipMemcpyHostToDevice, h->stream));
+    if ((rc = forward_tiles_dev(h, (const float*)h->ws_tiles.p, B, (float*)h->ws_out.p))) return rc;
+    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int msiren_recon_shape(msiren_handle h, int32_t height, int32_t width, int32_t* nv, int32_t* nh) {
+    if (!h) return fail(MSIREN_E_INVALID, "null handle");
+    if (height < 1 || width < 1) return fail(MSIREN_E_INVALID, "bad image size %dx%d", height, width);
+    if (nv) *nv = (height + h->I - 1) / h->I;
+    if (nh) *nh = (width + h->I - 1) / h->I;
+    return 0;
+}
+
+int msiren_image_to_patches_dev(msiren_handle h, const float* images_dev, int64_t n, int32_t height, int32_t width, float* patches_dev) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (n < 0 || height < 1 || width < 1) return fail(MSIREN_E_INVALID, "bad arguments");
+    if (n == 0) return 0;
+    const int pad = (h->O - h->I) / 2;
+    const int vpad = (h->I - height % h->I) % h->I, hpad = (h->I - width % h->I) % h->I;
+    // torch's reflect padding requires pad < dim (F.pad raises otherwise)
+    if (pad + vpad >= height || pad + hpad >= width)
+        return fail(MSIREN_E_INVALID, "image %dx%d is too small for reflect padding of %d/%d", height, width, pad + vpad, pad + hpad);
+    const int nV = (height + vpad) / h->I, nH = (width + hpad) / h->I;
+    const int64_t total = n * nV * nH * h->O * h->O;
+    hipLaunchKernelGGL(msiren::image_to_patches_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                       images_dev, patches_dev, n, height, width, nV, nH, h->O, h->I, pad);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev, int64_t n, int32_t nV, int32_t nH, float* recon_dev) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (n < 0 || nV < 1 || nH < 1) return fail(MSIREN_E_INVALID, "bad arguments");
+    if (n == 0) return 0;
+    const int64_t total = n * nV * h->I * (int64_t)nH * h->I;
+    hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                       tiles_dev, h->d_foldw, recon_dev, nullptr, n, nV, nH, h->S, h->I, (h->S - h->I) / 2);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int64_t n, int32_t height, int32_t width, float* recon_dev) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!images_dev || !recon_dev))) return fail(MSIREN_E_INVALID, "bad arguments");
+    if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles, outer_patch_size=%d", h->O);
+    if (n == 0) return 0;
+    int32_t nV, nH;
+    if ((rc = msiren_recon_shape(h, height, width, &nV, &nH))) return rc;
+    const int64_t NP = n * nV * nH;
+    if ((rc = ensure(h, h->ws_patches, (size_t)NP * h->O * h->O * sizeof(float)))) return rc;
+    if ((rc = ensure(h, h->ws_keep, (size_t)(NP + 64) * sizeof(int)))) return rc;
+    if ((rc = ensure(h, h->ws_rec, (size_t)NP * h->P * sizeof(float)))) return rc;
+    if ((rc = ensure(h, h->ws_latent, (size_t)NP * h->Z * sizeof(float)))) return rc;
+    if ((rc = ensure(h, h->ws_mods, (size_t)h->L * NP * h->H * sizeof(float)))) return rc;
+    float* patches = (float*)h->ws_patches.p;
+    int* black = (int*)h->ws_keep.p;
+    float* rec = (float*)h->ws_rec.p;
+    if ((rc = msiren_image_to_patches_dev(h, images_dev, n, height, width, patches))) return rc;
+    // The reference compacts the non-black tiles, runs the model, and scatters zeros back
+    // (tiling.py:244-303).  Patches are independent, so evaluating all of them in place and
+    // zeroing the black ones in the fold gives identical results without a device-side compaction.
+    hipLaunchKernelGGL(msiren::black_flags_kernel, dim3((unsigned)NP), dim3(256), 0, h->stream, patches, black, h->O * h->O);
+    HIPCHK(hipGetLastError());
+    if ((rc = launch_encoder(h, patches, NP, (float*)h->ws_latent.p))) return rc;
+    if ((rc = launch_modulator(h, (const float*)h->ws_latent.p, NP, (float*)h->ws_mods.p))) return rc;
+    if ((rc = launch_trunk(h, (const float*)h->ws_mods.p, NP, rec))) return rc;
+    const int64_t total = n * nV * h->I * (int64_t)nH * h->I;
+    hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                       rec, h->d_foldw, recon_dev, black, n, nV, nH, h->S, h->I, (h->S - h->I) / 2);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t n, int32_t height, int32_t width, float* recon_host) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!images_host || !recon_host))) return fail(MSIREN_E_INVALID, "bad arguments");
+    if (n == 0) return 0;
+    int32_t nV, nH;
+    if ((rc = msiren_recon_shape(h, height, width, &nV, &nH))) return rc;
+    const size_t ni = (size_t)n * height * width * sizeof(float);
+    const size_t nr = (size_t)n * nV * h->I * nH * h->I * sizeof(float);
+    if ((rc = ensure(h, h->ws_in, ni)) || (rc = ensure(h, h->ws_img, nr))) return rc;
+    HIPCHK(hipMemcpyAsync(h->ws_in.p, images_host, ni, hipMemcpyHostToDevice, h->stream));
+    if ((rc = msiren_reconstruct_slices_dev(h, (const float*)h->ws_in.p, n, height, width, (float*)h->ws_img.p))) return rc;
+    HIPCHK(hipMemcpyAsync(recon_host, h->ws_img.p, nr, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int msiren_sync(msiren_handle h) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int msiren_dev_alloc(msiren_handle h, size_t bytes, void** dev_ptr) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (!dev_ptr) return fail(MSIREN_E_INVALID, "null argument");
+    *dev_ptr = nullptr;
+    if (bytes == 0) return 0;
+    HIPCHK(hipMalloc(dev_ptr, bytes));
+    return 0;
+}
+
+int msiren_dev_free(msiren_handle h, void* dev_ptr) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (dev_ptr) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipFree(dev_ptr));
+    }
+    return 0;
+}
+
+int msiren_memcpy_h2d(msiren_handle h, void* dst_dev, const void* src_host, size_t bytes) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (bytes == 0) return 0;
+    HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int msiren_memcpy_d2h(msiren_handle h, void* dst_host, const void* src_dev, size_t bytes) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (bytes == 0) return 0;
+    HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int msiren_timer_start(msiren_handle h) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    return 0;
+}
+
+int msiren_timer_stop(msiren_handle h, float* elapsed_ms) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    return 0;
+}
+
+int msiren_profile_enable(msiren_handle h, int32_t on) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->profile = on != 0;
+    h->prof_used = 0;
+    h->prof_launches = 0;
+    h->prof_ms = 0.0;
+    return 0;
+}
+
+int msiren_profile_read(msiren_handle h, int64_t* launches, double* trunk_ms_total) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->prof_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->prof_events[i].first, h->prof_events[i].second));
+        h->prof_ms += ms;
+        h->prof_launches++;
+    }
+    h->prof_used = 0;
+    if (launches) *launches = h->prof_launches;
+    if (trunk_ms_total) *trunk_ms_total = h->prof_ms;
+    return 0;
+}
+
+int msiren_device_info(msiren_handle h, char* name256, int32_t* cus, int32_t* mhz, uint64_t* hbm) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, h->cfg.device));
+    if (name256) {
+        std::snprintf(name256, 256, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (mhz) *mhz = prop.clockRate / 1000;
+    if (hbm) *hbm = (uint64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+int msiren_flops_per_coord(msiren_handle h, double* flops) {
+    if (!h || !flops) return fail(MSIREN_E_INVALID, "null argument");
+    const double H = h->H, L = h->L;
+    *flops = 2.0 * 2.0 * H + (L - 1.0) * 2.0 * H * H + 2.0 * H;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+// Fused modulated-SIREN trunk for gfx950 (MI355X), exact-fp32 path.
+//
+// One launch evaluates SirenNet.forward (reference: src/networks/modulated_siren.py:215-233) for
+// every coordinate of every patch: layer 0 (K=2, VALU) -> L-1 hidden layers
+// (v_mfma_f32_32x32x2_f32) -> last_layer dot product (N=1) -> sine; activations never leave the CU.
+//
+// Work decomposition
+//   workgroup = 256 threads = 4 waves = one (patch b, chunk of 64 coordinates); grid = B * ceil(P/64).
+//   LDS holds the activation tile X as [k/4][coord 0..63][k%4] fp32 (HP*256 B): 64 KB at H=256, so
+//   two workgroups share a CU (one wave of each per SIMD): while one sits in its epilogue or at a
+//   barrier the other's MFMAs keep the matrix pipe busy.
+//   Each wave owns HP/4 output features (TT = HP/128 tiles of 32) for all 64 coordinates
+//   (2 column tiles): acc[TT][2] x 16 registers.  Per k-step of 8:
+//     A (weights)     : one global_load_dwordx4 per feature tile from the host-packed stream
+//                       Wp[layer][wave][q][tt][lane][4]  (1 KiB, fully coalesced, L2-resident;
+//                       every element is used by exactly one wave, so it never goes through LDS);
+//     B (activations) : one ds_read_b128 per column tile, conflict-free;
+//     4 steps x TT x 2 MFMAs (32x32x2): half-wave h supplies k = 8q + 4h + j at step j.
+//   The D layout (row = (r&3) + 8(r>>2) + 4h, col = lane&31) puts four consecutive features
+//   of one coordinate in registers 4g..4g+3, i.e. exactly one float4 of the X image:
+//   the epilogue is  bias -> act -> *mod -> ds_write_b128  with no shuffles.
+//
+// Scaling folded on the host (msiren.hip: pack_trunk): all weights/biases are pre-multiplied by
+// w0/(2*pi) (w0_initial for layer 0) so that the accumulator is the sine argument in REVOLUTIONS,
+// the unit v_sin_f32 takes.  Morlet's Gaussian exp(-p^2/2) becomes exp2(cg * r^2).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace msiren {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct TrunkParams {
+    const float* grid;   // (P,2) coordinates (the state_dict's "grid" buffer)
+    const float* l0;     // (HP,4): {w_row*c0, w_col*c0, b*c0, 0}
+    const float* wp;     // packed hidden weights, see above
+    const float* bias;   // (L-1, HP), scaled
+    const float* wout;   // (HP), scaled
+    const float* mods;   // (L, B, mod_stride)
+    float* out;          // (B, P)
+    float bout;          // scaled
+    float cg0, cg;       // Morlet Gaussian constants for layer 0 / hidden layers
+    int B, P, L, mod_stride, chunks;
+};
+
+// sin(2*pi*r): explicit round-to-nearest reduction (exact in fp32), then the hardware sine.
+__device__ __forceinline__ float sin_rev(float r) {
+    float f = r - __builtin_rintf(r);
+    return __builtin_amdgcn_sinf(f);
+}
+
+template <int ACT>
+__device__ __forceinline__ float activate(float r, float cg) {
+    if constexpr (ACT == 1) {
+        return sin_rev(r) * __builtin_amdgcn_exp2f(cg * r * r);
+    } else {
+        return sin_rev(r);
+    }
+}
+
+template <int HP, int ACT, int RES>
+__global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kernel(TrunkParams p) {
+    constexpr int TT = HP / 128;  // 32-feature tiles per wave
+    constexpr int QN = HP / 8;    // k-iterations of 8
+    constexpr int KG = HP / 4;    // k-groups of 4 (rows of the X image)
+    static_assert(HP % 128 == 0, "hidden width is padded to a multiple of 128");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    f32x4* X = reinterpret_cast<f32x4*>(lds);  // X[kg*64 + coord]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int c32 = lane & 31;
+    const int b = blockIdx.x / p.chunks;
+    const int ch = blockIdx.x - b * p.chunks;
+    const int L = p.L;
+
+    // ---------------- layer 0: K = 2, straight into the X image --------------------------------
+    {
+        int pc = ch * 64 + lane;
+        pc = pc < p.P ? pc : p.P - 1;
+        const float2 xy = reinterpret_cast<const float2*>(p.grid)[pc];
+        const float* mod0 = p.mods + (size_t)b * p.mod_stride;
+        const f32x4* l0 = reinterpret_cast<const f32x4*>(p.l0);
+#pragma unroll 2
+        for (int i = 0; i < KG / 4; ++i) {
+            const int kg = wave * (KG / 4) + i;
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mod0 + 4 * kg);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 w = l0[4 * kg + e];
+                const float r = __builtin_fmaf(xy.y, w.y, __builtin_fmaf(xy.x, w.x, w.z));
+                v[e] = activate<ACT>(r, p.cg0) * m[e];
+            }
+            X[kg * 64 + lane] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- hidden layers 1..L-1 on the matrix cores ---------------------------------
+    const int fwave = wave * (32 * TT);  // first feature owned by this wave
+    float part[2] = {0.f, 0.f};          // last_layer partial sums (used on the final hidden layer)
+
+    for (int l = 1; l < L; ++l) {
+        const f32x4* wA = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)(l - 1) * 4 + wave) * (QN * TT * 64) + lane;
+        const float* bl = p.bias + (size_t)(l - 1) * HP;
+        const float* ml = p.mods + ((size_t)l * p.B + b) * p.mod_stride;
+
+        // per-feature constants of this wave's rows: issued now, consumed in the epilogue
+        f32x4 bias_r[TT][4], mod_r[TT][4];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int fo = fwave + 32 * tt + 8 * g + 4 * half;
+                bias_r[tt][g] = *reinterpret_cast<const f32x4*>(bl + fo);
+                mod_r[tt][g] = *reinterpret_cast<const f32x4*>(ml + fo);
+            }
+
+        f32x16 acc[TT][2];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int jc = 0; jc < 2; ++jc)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tt][jc][r] = 0.f;
+
+        const f32x4* xB = X + half * 64 + c32;  // + (2q)*64 + 32*jc
+
+        f32x4 a0[TT], a1[TT], b0[2], b1[2];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) a0[tt] = wA[tt * 64];
+        b0[0] = xB[0];
+        b0[1] = xB[32];
+
+        auto mma = [&](const f32x4(&a)[TT], const f32x4(&bb)[2]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                    for (int jc = 0; jc < 2; ++jc)
+                        acc[tt][jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt][j], bb[jc][j], acc[tt][jc], 0, 0, 0);
+        };
+
+        // Software pipeline, distance one k-step (16 MFMAs ~ 1024 cycles): the loads of step q+1 are
+        // issued before the MFMAs of step q.  sched_barrier pins that order -- without it hipcc sinks
+        // every load down to its first use and exposes the L2 latency once per 8 MFMAs.
+#pragma nounroll
+        for (int q = 0; q < QN; q += 2) {
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) a1[tt] = wA[((q + 1) * TT + tt) * 64];
+            b1[0] = xB[(2 * (q + 1)) * 64];
+            b1[1] = xB[(2 * (q + 1)) * 64 + 32];
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < QN) {
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) a0[tt] = wA[((q + 2) * TT + tt) * 64];
+                b0[0] = xB[(2 * (q + 2)) * 64];
+                b0[1] = xB[(2 * (q + 2)) * 64 + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        __syncthreads();  // every wave has finished reading X: rows may now be overwritten
+
+        const int kgw = wave * (8 * TT);
+        if (l < L - 1) {
+            // epilogue: bias -> activation -> modulation, back into this wave's rows of the X image
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int jc = 0; jc < 2; ++jc) {
+                        const int xi = (kgw + 8 * tt + 2 * g + half) * 64 + 32 * jc + c32;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float r = acc[tt][jc][4 * g + e] + bias_r[tt][g][e];
+                            v[e] = activate<ACT>(r, p.cg) * mod_r[tt][g][e];
+                        }
+                        if constexpr (RES) v += X[xi];
+                        X[xi] = v;
+                    }
+            __syncthreads();
+        } else {
+            // final hidden layer: its output feeds last_layer's dot product straight from registers
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 wo = *reinterpret_cast<const f32x4*>(p.wout + fwave + 32 * tt + 8 * g + 4 * half);
+#pragma unroll
+                    for (int jc = 0; jc < 2; ++jc) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float r = acc[tt][jc][4 * g + e] + bias_r[tt][g][e];
+                            v[e] = activate<ACT>(r, p.cg) * mod_r[tt][g][e];
+                        }
+                        if constexpr (RES) v += X[(kgw + 8 * tt + 2 * g + half) * 64 + 32 * jc + c32];
+                        part[jc] += v[0] * wo[0] + v[1] * wo[1] + v[2] * wo[2] + v[3] * wo[3];
+                    }
+                }
+        }
+    }
+
+    // ---------------- last_layer: dot over H features, always sine -----------------------------
+    float* red = lds;  // [4][64], X is dead (or, for L == 1, read below before the barrier)
+    if (L == 1) {
+        // no hidden layer ran: take the dot product from the X image (coord = lane, kgs split by wave)
+        float s = 0.f;
+        for (int i = 0; i < KG / 4; ++i) {
+            const int kg = wave * (KG / 4) + i;
+            const f32x4 v = X[kg * 64 + lane];
+            const f32x4 wo = *reinterpret_cast<const f32x4*>(p.wout + 4 * kg);
+            s += v[0] * wo[0] + v[1] * wo[1] + v[2] * wo[2] + v[3] * wo[3];
+        }
+        __syncthreads();
+        red[wave * 64 + lane] = s;
+    } else {
+        part[0] += __shfl_xor(part[0], 32);
+        part[1] += __shfl_xor(part[1], 32);
+        // (the barrier after the K loop already separates the last X reads from these writes,
+        //  except for RES, whose epilogue reads X: add one)
+        if constexpr (RES) __syncthreads();
+        if (half == 0) {
+            red[wave * 64 + c32] = part[0];
+            red[wave * 64 + 32 + c32] = part[1];
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float s = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid] + p.bout;
+        const int pc = ch * 64 + tid;
+        if (pc < p.P) p.out[(size_t)b * p.P + pc] = sin_rev(s);
+    }
+}
+
+}  // namespace msiren

@@ -1,0 +1,87 @@
+// The steps either side of the model call (reference: src/util/tiling.py), as gather kernels:
+// every output element is computed by one thread from at most a handful of inputs, so there are
+// no atomics and results do not depend on scheduling.  All of this is HBM-bound byte moving:
+// the kernels only have to keep accesses coalesced along the fastest output axis.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace msiren {
+
+// dst[r, 0:HP] = {src[r, 0:H], 0...}
+__global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int H, int HP) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * HP) return;
+    const int64_t r = i / HP;
+    const int c = (int)(i - r * HP);
+    dst[i] = c < H ? src[r * H + c] : 0.f;
+}
+
+// image_to_patches (tiling.py:10-64): reflect-pad by `pad` on every side plus bottom/right up to a
+// multiple of I, then O x O windows at stride I, row-major over (nV, nH).
+__global__ void image_to_patches_kernel(const float* __restrict__ img, float* __restrict__ patches, int64_t n, int Hh, int Ww,
+                                        int nV, int nH, int O, int I, int pad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_slice = (int64_t)nV * nH * O * O;
+    if (i >= n * per_slice) return;
+    const int64_t s = i / per_slice;
+    int64_t r = i - s * per_slice;
+    const int x = (int)(r % O);
+    r /= O;
+    const int y = (int)(r % O);
+    r /= O;
+    const int hh = (int)(r % nH);
+    const int v = (int)(r / nH);
+    int sy = v * I + y - pad, sx = hh * I + x - pad;
+    sy = sy < 0 ? -sy : sy;
+    sy = sy >= Hh ? 2 * (Hh - 1) - sy : sy;
+    sx = sx < 0 ? -sx : sx;
+    sx = sx >= Ww ? 2 * (Ww - 1) - sx : sx;
+    patches[i] = img[(s * Hh + sy) * Ww + sx];
+}
+
+// classify_patches (tiling.py:184-198): mean < 1e-10  ->  black (flag 1).  One workgroup per patch.
+__global__ __launch_bounds__(256) void black_flags_kernel(const float* __restrict__ patches, int* __restrict__ flags, int elems) {
+    __shared__ float red[4];
+    const float* p = patches + (size_t)blockIdx.x * elems;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < elems; i += 256) s += p[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)elems;
+        flags[blockIdx.x] = mean < 1e-10f ? 1 : 0;
+    }
+}
+
+// patches_to_image_weighted_average (tiling.py:91-140): fold(tiles * w) / fold(w) with kernel S,
+// stride I, padding `pad`.  Black patches (flags[b] != 0) contribute zeros with their full weight,
+// as reintegrate_black_patches + fold do in the reference (tiling.py:287-301, :117-118).
+__global__ void weighted_fold_kernel(const float* __restrict__ tiles, const float* __restrict__ w, float* __restrict__ recon,
+                                     const int* __restrict__ flags, int64_t n, int nV, int nH, int S, int I, int pad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int OH = nV * I, OW = nH * I;
+    if (i >= n * OH * (int64_t)OW) return;
+    const int64_t s = i / ((int64_t)OH * OW);
+    const int r = (int)(i - s * (int64_t)OH * OW);
+    const int Y = r / OW, Xc = r - Y * OW;
+    const int py = Y + pad, px = Xc + pad;
+    int v0 = py - S + 1;
+    v0 = v0 <= 0 ? 0 : (v0 + I - 1) / I;
+    int h0 = px - S + 1;
+    h0 = h0 <= 0 ? 0 : (h0 + I - 1) / I;
+    const int v1 = min(nV - 1, py / I), h1 = min(nH - 1, px / I);
+    float num = 0.f, den = 0.f;
+    for (int v = v0; v <= v1; ++v)
+        for (int hh = h0; hh <= h1; ++hh) {
+            const int ty = py - v * I, tx = px - hh * I;
+            const int64_t b = (s * nV + v) * nH + hh;
+            const float ww = w[ty * S + tx];
+            den += ww;
+            if (!flags || flags[b] == 0) num += tiles[(b * S + ty) * S + tx] * ww;
+        }
+    recon[i] = num / den;
+}
+
+}  // namespace msiren

@@ -1,0 +1,90 @@
+"""Multi-GPU layer: one process per GPU, patches/slices sharded, weights broadcast once.
+
+The forward pass has no exchange step -- every patch is independent given the (replicated, ~4 MB)
+weights -- so the only collective is one broadcast of the weight blob from the source rank at load
+time (RCCL over xGMI when the process group is "nccl"; "gloo" in the CPU tests).  Outputs stay on
+the GPU that produced them; ``gather_outputs`` exists for callers that want them on one rank.
+
+The reference is single-process; this is the scale-out the north star asks for.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n_items: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous block partition: the first ``n % world`` ranks get one extra item."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, extra = divmod(int(n_items), world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _layout(sd: dict):
+    keys = sorted(sd.keys())
+    return [(k, tuple(sd[k].shape)) for k in keys]
+
+
+def broadcast_state_dict(sd: dict | None, src: int = 0, device=None, group=None) -> dict:
+    """Broadcast a ``{key: float32 ndarray}`` state_dict from ``src`` to every rank.
+
+    Metadata (keys, shapes) travels as a Python object; the payload as ONE flat float32 tensor --
+    a single collective of ~4 MB rather than one per tensor (xGMI broadcast is latency-bound at
+    this size).  ``device``: torch device of the staging tensor (a CUDA device for nccl/RCCL,
+    None/cpu for gloo).
+    """
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    meta = [_layout(sd)] if rank == src else [None]
+    dist.broadcast_object_list(meta, src=src, group=group)
+    layout = meta[0]
+    total = int(sum(int(np.prod(s, dtype=np.int64)) for _, s in layout))
+    dev = device if device is not None else torch.device("cpu")
+    if rank == src:
+        flat = np.concatenate([np.ascontiguousarray(sd[k], dtype=np.float32).reshape(-1) for k, _ in layout])
+        buf = torch.from_numpy(flat).to(dev)
+    else:
+        buf = torch.empty(total, dtype=torch.float32, device=dev)
+    dist.broadcast(buf, src=src, group=group)
+    host = buf.cpu().numpy()
+    out, off = {}, 0
+    for k, shp in layout:
+        n = int(np.prod(shp, dtype=np.int64))
+        out[k] = host[off:off + n].reshape(shp).copy()
+        off += n
+    return out
+
+
+def gather_outputs(local: np.ndarray, n_total: int, dst: int = 0, group=None):
+    """Collect per-rank output blocks (block partition of axis 0, see :func:`shard_range`) on ``dst``."""
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(np.ascontiguousarray(local), parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = np.concatenate(parts, axis=0)
+    assert out.shape[0] == n_total, (out.shape, n_total)
+    return out
+
+
+def sharded_forward(model, tiles: np.ndarray, group=None, gather: bool = True):
+    """Evaluate ``model`` on this rank's contiguous block of ``tiles`` (B, O, O).
+
+    Returns the full (B, S, S) array on rank 0 (None elsewhere) when ``gather`` is set, otherwise
+    the local block and its (lo, hi) range.  ``model`` is any callable tiles -> outputs, so the CPU
+    tests can exercise the partition/gather logic with a stand-in.
+    """
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_range(tiles.shape[0], rank, world)
+    local = np.asarray(model(tiles[lo:hi]))
+    if not gather:
+        return local, (lo, hi)
+    return gather_outputs(local, tiles.shape[0], 0, group)

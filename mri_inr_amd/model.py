@@ -1,0 +1,376 @@
+"""``ModulatedSiren`` -- host-side mirror of the reference's model interface, backed by libmsiren.
+
+Drop-in for the class of the same name in the reference (src/networks/modulated_siren.py:346-457)
+as used by its evaluation path (test_mod_siren.py:96-120, src/util/error.py:138,235):
+
+    model = ModulatedSiren(**17 kwargs)          # same names, same meaning
+    model.load_state_dict(sd)                    # same keys/shapes
+    model.to(device); model.eval()
+    out = model(tiles)                           # (B, O, O) float32 -> (B, S, S) float32
+
+Arrays may be numpy arrays or torch tensors (CPU or ROCm device tensors, which are consumed and
+produced in place through their ``data_ptr()``); the result has the type of the input.  All
+arithmetic happens in hand-written gfx950 kernels behind the C ABI of ``include/msiren.h``; there
+is no PyTorch or numpy compute on this path and no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import collections
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from . import synthetic
+
+_ACT = {"sine": _lib.ACT_SINE, "morlet": _lib.ACT_MORLET}
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+def _device_index(device) -> int | None:
+    """'cuda', 'cuda:1', 1, torch.device('cuda', 1) -> ordinal; 'cpu' -> None."""
+    if device is None:
+        return 0
+    if isinstance(device, (int, np.integer)):
+        return int(device)
+    s = str(device)
+    if s.startswith("cpu"):
+        return None
+    if s.startswith(("cuda", "hip")):
+        return int(s.split(":")[1]) if ":" in s else 0
+    raise ValueError(f"unknown device {device!r}")
+
+
+class DeviceArray:
+    """A float32 array in HBM owned through the C ABI (msiren_dev_alloc / msiren_dev_free)."""
+
+    def __init__(self, model: "ModulatedSiren", shape):
+        self.model = model
+        self.shape = tuple(int(s) for s in shape)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * 4
+        p = C.c_void_p()
+        _lib.check(model._lib.msiren_dev_alloc(model._h, self.nbytes, C.byref(p)))
+        self.ptr = p.value or 0
+
+    def copy_from(self, host: np.ndarray):
+        host = np.ascontiguousarray(host, dtype=np.float32)
+        assert host.nbytes == self.nbytes, (host.shape, self.shape)
+        _lib.check(self.model._lib.msiren_memcpy_h2d(self.model._h, self.ptr, host.ctypes.data, self.nbytes))
+        return self
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float32)
+        _lib.check(self.model._lib.msiren_memcpy_d2h(self.model._h, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr and self.model._h:
+            self.model._lib.msiren_dev_free(self.model._h, self.ptr)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ModulatedSiren:
+    """See module docstring.  Constructor signature: modulated_siren.py:349-368."""
+
+    def __init__(self, dim_in, dim_hidden, dim_out, num_layers, latent_dim, w0, w0_initial, use_bias,
+                 dropout, modulate, encoder_type, encoder_path, outer_patch_size, inner_patch_size,
+                 siren_patch_size, device, activation, *, residual=False, precision="fp32"):
+        # attribute names as in the reference (:389-398)
+        self.dim_in = int(dim_in)
+        self.dim_hidden = int(dim_hidden)
+        self.dim_out = int(dim_out)
+        self.num_layers = int(num_layers)
+        self.latent_dim = int(latent_dim)
+        self.w0 = float(w0)
+        self.w0_initial = float(w0_initial)
+        self.use_bias = bool(use_bias)
+        self.dropout = float(dropout)  # identity in eval mode; kept for signature parity
+        self.modulate = modulate        # stored and never read, as in the reference (:397)
+        self.encoder_type = encoder_type
+        self.encoder_path = encoder_path
+        self.outer_patch_size = int(outer_patch_size)
+        self.inner_patch_size = int(inner_patch_size)
+        self.siren_patch_size = int(siren_patch_size)
+        self.activation = activation
+        self.residual = bool(residual)
+        self.precision = precision
+        self.training = True
+        if self.dim_in != 2:
+            raise ValueError(f"dim_in must be 2 (the coordinate grid is a 2-D meshgrid), got {dim_in}")
+        if self.dim_out != 1:
+            raise ValueError(f"dim_out must be 1 (squeeze(2)+rearrange in the reference forward), got {dim_out}")
+        if encoder_type == "vgg":
+            raise NotImplementedError("encoder_type='vgg' (ablation encoder, src/networks/encoding/vgg.py) is out of "
+                                      "scope of the MI355X path; use encoder_type='custom'")
+        self._lib = None
+        self._h = None
+        self._device = _device_index(device)
+        self._committed = False
+        # a fresh model has random weights, like a fresh nn.Module
+        sd = synthetic.make_state_dict(seed=0, dim_hidden=self.dim_hidden, num_layers=self.num_layers,
+                                       latent_dim=self.latent_dim, w0=self.w0,
+                                       siren_patch_size=self.siren_patch_size, use_bias=self.use_bias,
+                                       with_encoder=(self.outer_patch_size == 32))
+        if encoder_type != "custom":
+            # reference: no `encoder` attribute is created for other types (:252-262) -> forward fails
+            sd = {k: v for k, v in sd.items() if not k.startswith("encoder.")}
+        elif encoder_path is not None:
+            sd.update(self._load_encoder_checkpoint(encoder_path))
+        self._sd = collections.OrderedDict(sd)
+        self.grid = self._sd["grid"]
+        if self._device is not None and _lib_device_available():
+            self._ensure_handle()
+
+    # ------------------------------------------------------------------ nn.Module-like protocol --
+    def _load_encoder_checkpoint(self, path):
+        """FixedEncoder: torch.load(path)["state_dict"] of a FixedAutoencoder (siren_encoder.py:544-549)."""
+        from .weights import load_checkpoint
+
+        raw = load_checkpoint(os.fspath(path))
+        raw = raw["state_dict"] if "state_dict" in raw else raw
+        out = {}
+        for k, v in raw.items():
+            if k.startswith("encoder."):
+                out["encoder.encoder." + k] = np.ascontiguousarray(v, dtype=np.float32)
+        return out
+
+    def _config(self) -> _lib.MsirenConfig:
+        if self.activation not in _ACT:
+            # the reference treats anything but "morlet" as sine (:120-123)
+            act = _lib.ACT_SINE
+        else:
+            act = _ACT[self.activation]
+        cfg = _lib.MsirenConfig()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.dim_in, cfg.dim_hidden, cfg.dim_out = self.dim_in, self.dim_hidden, self.dim_out
+        cfg.num_layers, cfg.latent_dim = self.num_layers, self.latent_dim
+        cfg.w0, cfg.w0_initial = self.w0, self.w0_initial
+        cfg.use_bias = int(self.use_bias)
+        cfg.activation = act
+        cfg.outer_patch_size, cfg.inner_patch_size = self.outer_patch_size, self.inner_patch_size
+        cfg.siren_patch_size = self.siren_patch_size
+        cfg.residual = int(self.residual)
+        cfg.precision = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}[self.precision]
+        cfg.device = int(self._device or 0)
+        return cfg
+
+    def _ensure_handle(self):
+        if self._h is not None:
+            return
+        if self._device is None:
+            raise _lib.MsirenError("ModulatedSiren has no CPU path: move it to a gfx950 device with .to('cuda')")
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        cfg = self._config()
+        _lib.check(self._lib.msiren_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._committed = False
+
+    def _ensure_committed(self):
+        self._ensure_handle()
+        if self._committed:
+            return
+        for k, v in self._sd.items():
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            _lib.check(self._lib.msiren_set_tensor(self._h, k.encode(), a.ctypes.data, a.size))
+        _lib.check(self._lib.msiren_commit_weights(self._h))
+        self._committed = True
+
+    def expected_keys(self):
+        return list(self._sd.keys())
+
+    def state_dict(self):
+        return collections.OrderedDict((k, np.array(v, copy=True)) for k, v in self._sd.items())
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Same contract as nn.Module.load_state_dict: key set and shapes must match."""
+        new = {}
+        for k, v in state_dict.items():
+            if _is_torch(v):
+                v = v.detach().cpu().numpy()
+            new[k] = np.ascontiguousarray(v, dtype=np.float32)
+        missing = [k for k in self._sd if k not in new]
+        unexpected = [k for k in new if k not in self._sd]
+        errs = []
+        if strict and unexpected:
+            errs.append("Unexpected key(s) in state_dict: " + ", ".join(f'"{k}"' for k in unexpected) + ". ")
+        if strict and missing:
+            errs.append("Missing key(s) in state_dict: " + ", ".join(f'"{k}"' for k in missing) + ". ")
+        for k, v in new.items():
+            if k in self._sd and tuple(v.shape) != tuple(self._sd[k].shape):
+                errs.append(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from checkpoint, "
+                            f"the shape in current model is {tuple(self._sd[k].shape)}.")
+        if errs:
+            raise RuntimeError("Error(s) in loading state_dict for ModulatedSiren:\n\t" + "\n\t".join(errs))
+        for k, v in new.items():
+            if k in self._sd:
+                self._sd[k] = v
+        self.grid = self._sd["grid"]
+        self._committed = False
+        if self._h is not None:
+            self._ensure_committed()
+        return collections.namedtuple("IncompatibleKeys", "missing_keys unexpected_keys")(missing, unexpected)
+
+    def to(self, device):
+        idx = _device_index(device)
+        if idx is None:
+            raise _lib.MsirenError("ModulatedSiren (MI355X build) has no CPU path; .to('cpu') is not supported")
+        if idx != self._device and self._h is not None:
+            self._lib.msiren_destroy(self._h)
+            self._h = None
+        self._device = idx
+        self._ensure_committed()
+        return self
+
+    def cuda(self, device=None):
+        return self.to(0 if device is None else device)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        # the reference's train mode only switches on nn.Dropout(0.1) (:156); inference path only
+        if mode:
+            raise NotImplementedError("the MI355X path implements eval-mode inference only")
+        self.training = False
+        return self
+
+    def parameters(self):
+        return [v for k, v in self._sd.items() if k != "grid"]
+
+    def __del__(self):
+        try:
+            if self._h is not None and self._lib is not None:
+                self._lib.msiren_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # --------------------------------------------------------------------------------- forward --
+    def _run(self, host_fn, dev_fn, x, in_tail, out_shape_fn, extra_null=0):
+        """Common marshalling: numpy / torch-cpu -> host entry point; torch device tensor -> *_dev."""
+        self._ensure_committed()
+        S = self.siren_patch_size
+        if _is_torch(x):
+            import torch
+
+            if x.is_cuda:
+                if x.device.index != self._device:
+                    raise ValueError(f"input is on cuda:{x.device.index}, model on cuda:{self._device}")
+                xx = x.detach().to(torch.float32).contiguous()
+                self._check_tail(tuple(xx.shape), in_tail)
+                B = out_shape_fn(tuple(xx.shape))
+                out = torch.empty((B, S, S), dtype=torch.float32, device=x.device)
+                torch.cuda.current_stream(x.device).synchronize()
+                args = [self._h, xx.data_ptr(), B, out.data_ptr()] + [None] * extra_null
+                _lib.check(dev_fn(*args))
+                _lib.check(self._lib.msiren_sync(self._h))
+                return out
+            res = self._run(host_fn, dev_fn, x.detach().cpu().numpy(), in_tail, out_shape_fn, extra_null)
+            return torch.from_numpy(res)
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        self._check_tail(a.shape, in_tail)
+        B = out_shape_fn(a.shape)
+        out = np.empty((B, S, S), dtype=np.float32)
+        args = [self._h, a.ctypes.data if a.size else None, B, out.ctypes.data if out.size else None] + [None] * extra_null
+        _lib.check(host_fn(*args))
+        return out
+
+    @staticmethod
+    def _check_tail(shape, tail):
+        if len(shape) != len(tail) or any(t is not None and s != t for s, t in zip(shape, tail)):
+            want = tuple("B" if t is None else t for t in tail)
+            raise ValueError(f"expected input of shape {want}, got {tuple(shape)}")
+
+    def forward(self, tiles):
+        """tiles (B, O, O) -> (B, S, S).  Reference: modulated_siren.py:435-457."""
+        if self.encoder_type != "custom":
+            raise AttributeError("'Encoder' object has no attribute 'encoder'")  # as the reference fails
+        O = self.outer_patch_size
+        self._ensure_handle()
+        return self._run(self._lib.msiren_forward_tiles, self._lib.msiren_forward_tiles_dev, tiles,
+                         (None, O, O), lambda s: s[0])
+
+    __call__ = forward
+
+    def forward_latent(self, z):
+        """latent (B, Z) -> (B, S, S): Modulator + SirenNet (modulated_siren.py:325-343, 215-233)."""
+        self._ensure_handle()
+        return self._run(self._lib.msiren_forward_latent, self._lib.msiren_forward_latent_dev, z,
+                         (None, self.latent_dim), lambda s: s[0], extra_null=1)
+
+    def forward_mods(self, mods):
+        """mods (L, B, H) (or the Modulator's tuple of L arrays (B, H)) -> (B, S, S)."""
+        if isinstance(mods, (tuple, list)):
+            if _is_torch(mods[0]):
+                import torch
+
+                mods = torch.stack(list(mods), 0)
+            else:
+                mods = np.stack([np.asarray(m) for m in mods], 0)
+        self._ensure_handle()
+        return self._run(self._lib.msiren_forward_mods, self._lib.msiren_forward_mods_dev, mods,
+                         (self.num_layers, None, self.dim_hidden), lambda s: s[1])
+
+    def reconstruct(self, images):
+        """images (n, Hh, Ww) or (Hh, Ww) -> (n, nV*I, nH*I): the whole slice pipeline of
+        metrics_error (src/util/error.py:231-249) on the device."""
+        self._ensure_committed()
+        a = images.detach().cpu().numpy() if _is_torch(images) else np.asarray(images)
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        single = a.ndim == 2
+        if single:
+            a = a[None]
+        if a.ndim != 3:
+            raise ValueError(f"expected (n, H, W) images, got {a.shape}")
+        n, Hh, Ww = a.shape
+        nv, nh = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.msiren_recon_shape(self._h, Hh, Ww, C.byref(nv), C.byref(nh)))
+        I = self.inner_patch_size
+        out = np.empty((n, nv.value * I, nh.value * I), dtype=np.float32)
+        _lib.check(self._lib.msiren_reconstruct_slices(self._h, a.ctypes.data, n, Hh, Ww, out.ctypes.data))
+        res = out[0] if single else out
+        if _is_torch(images):
+            import torch
+
+            return torch.from_numpy(res)
+        return res
+
+    # -------------------------------------------------------------------- low-level helpers ----
+    def device_array(self, shape) -> DeviceArray:
+        self._ensure_handle()
+        return DeviceArray(self, shape)
+
+    def sync(self):
+        self._ensure_handle()
+        _lib.check(self._lib.msiren_sync(self._h))
+
+    def device_info(self) -> dict:
+        self._ensure_handle()
+        name = C.create_string_buffer(256)
+        cus, mhz, hbm = C.c_int32(), C.c_int32(), C.c_uint64()
+        _lib.check(self._lib.msiren_device_info(self._h, name, C.byref(cus), C.byref(mhz), C.byref(hbm)))
+        return dict(name=name.value.decode(), compute_units=cus.value, clock_mhz=mhz.value, hbm_bytes=hbm.value)
+
+    def flops_per_coord(self) -> float:
+        H, L = self.dim_hidden, self.num_layers
+        return float(2 * 2 * H + (L - 1) * 2 * H * H + 2 * H)
+
+
+def _lib_device_available() -> bool:
+    try:
+        return _lib.device_count() > 0
+    except Exception:
+        return False

@@ -251,8 +251,11 @@ def main():
             import src.configuration.configuration as rc  # type: ignore
             rc = importlib.reload(rc)
             try:
+                import yaml
+                with open(path) as fh:
+                    user = yaml.safe_load(fh)  # the loader's input, as data
                 ns = rc.load_configuration(path, testing=testing)
-                cfgs[rel] = dict(testing=testing, config=rc.namespace_to_dict(ns))
+                cfgs[rel] = dict(testing=testing, user=user, config=rc.namespace_to_dict(ns))
             except Exception as e:  # pragma: no cover
                 cfgs[rel] = dict(testing=testing, error=f"{type(e).__name__}: {e}")
     with open(os.path.join(GOLD, "configs.json"), "w") as fh:

@@ -1,0 +1,188 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference-generated golden fixtures
+and against the CPU oracle on seeded inputs.
+
+Gate: max|gpu - ref| / max|ref| <= 1e-4 and RMS <= 1e-5 for the
+fp32 configurations.  The oracle is the checker only; nothing here feeds it into the product.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, nerr, rms
+from mri_inr_amd import ModulatedSiren, synthetic as syn
+from oracle import siren_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+RMS_TOL = 1e-5
+
+
+def make_model(sd, *, H=256, L=5, Z=256, S=24, act="sine", use_bias=True, **kw):
+    m = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=kw.pop("w0", 1.0),
+                       w0_initial=kw.pop("w0_initial", 30.0), use_bias=use_bias, dropout=0.1, modulate=True,
+                       encoder_type="custom", encoder_path=None, outer_patch_size=32, inner_patch_size=16,
+                       siren_patch_size=S, device="cuda", activation=act, **kw)
+    m.load_state_dict(sd)
+    m.to("cuda")
+    m.eval()
+    return m
+
+
+def check(out, ref, tol=TOL, rtol=RMS_TOL):
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert out.dtype == np.float32
+    assert np.isfinite(out).all()
+    e, r = nerr(out, ref), rms(out, ref)
+    assert e <= tol and r <= rtol, (e, r)
+    return e
+
+
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_trunk_vs_reference_fixtures(act):
+    g = load_golden(f"trunk_{act}.npz")
+    sd = syn.make_state_dict(seed=7)
+    m = make_model(sd, act=act)
+    cases = {
+        "uniform_B1": syn.make_mods(31, 5, 1, 256),
+        "uniform_B64": syn.make_mods(32, 5, 64, 256),
+        "sparse_B16": syn.make_mods(33, 5, 16, 256, lo=0.0, hi=2.0, zero_fraction=0.5),
+        "modulator_B16": g["modulator_mods"],
+    }
+    for name, mods in cases.items():
+        out = m.forward_mods(mods)
+        assert out.shape == (mods.shape[1], 24, 24)
+        check(out.reshape(out.shape[0], -1), g[name])
+    # the modulator's tuple form is accepted as well
+    out2 = m.forward_mods(tuple(cases["uniform_B64"][l] for l in range(5)))
+    assert np.array_equal(out2, m.forward_mods(cases["uniform_B64"]))
+
+
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_tiny_vs_reference_fixture(act):
+    g = load_golden(f"tiny_{act}.npz")
+    meta = json.loads(str(g["meta"]))
+    sd = syn.make_state_dict(seed=meta["seed"], dim_hidden=meta["H"], num_layers=meta["L"],
+                             latent_dim=meta["Z"], siren_patch_size=meta["S"])
+    m = make_model(sd, H=meta["H"], L=meta["L"], Z=meta["Z"], S=meta["S"], act=act)
+    mods = syn.make_mods(meta["mods_seed"], meta["L"], meta["B"], meta["H"])
+    out = m.forward_mods(mods)
+    check(out.reshape(meta["B"], -1), g["out"])
+
+
+@pytest.mark.parametrize("preset", ["default", "trained"])
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_forward_tiles_and_latent_vs_reference(preset, act):
+    g = load_golden(f"forward_{preset}_{act}.npz")
+    sd = syn.make_state_dict(seed=7, trained_like=(preset == "trained"))
+    m = make_model(sd, act=act)
+    tiles = np.random.default_rng(42).random((8, 32, 32), dtype=np.float32)
+    out = m(tiles)
+    check(out, g["out"])
+    out_l = m.forward_latent(g["latent"])
+    check(out_l, g["out"])
+    out_m = m.forward_mods(g["mods"])
+    check(out_m, g["out"])
+
+
+def test_slice_reconstruction_vs_reference():
+    g = load_golden("slice_recon.npz")
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = make_model(sd)
+    img = syn.make_slice(0, 160, 128, brain_mask=True)
+    rec = m.reconstruct(img)
+    check(rec, g["image"][0])
+    rec2 = m.reconstruct(np.stack([img, syn.make_slice(1, 160, 128)]))
+    assert rec2.shape == (2, 160, 128)
+    assert np.array_equal(rec2[0], rec)
+
+
+@pytest.mark.parametrize("H,L,S,B,act,bias", [
+    (256, 5, 24, 400, "sine", True),     # config 2: one 320x320 slice
+    (256, 5, 24, 7, "morlet", True),
+    (256, 1, 24, 3, "sine", True),       # no hidden layer at all
+    (256, 2, 24, 3, "sine", False),      # use_bias=False
+    (100, 3, 10, 5, "sine", True),       # padded hidden width, ragged last coordinate chunk
+    (128, 4, 9, 2, "morlet", True),
+    (384, 3, 12, 2, "sine", True),
+    (512, 3, 8, 2, "sine", True),
+])
+def test_trunk_vs_oracle_shapes(H, L, S, B, act, bias):
+    sd = syn.make_state_dict(seed=3, dim_hidden=H, num_layers=L, siren_patch_size=S, use_bias=bias, with_encoder=False)
+    sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
+    m = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=256, w0=1.0, w0_initial=30.0,
+                       use_bias=bias, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=S, device="cuda", activation=act)
+    m.load_state_dict(sd, strict=False)
+    m.to("cuda")
+    mods = syn.make_mods(5, L, B, H)
+    out = m.forward_mods(mods)
+    ref64 = orc.siren_forward(sd, mods, num_layers=L, activation=act, siren_patch_size=S, dtype=np.float64)
+    ref32 = orc.siren_forward(sd, mods, num_layers=L, activation=act, siren_patch_size=S)
+    e64 = check(out.reshape(B, -1), ref64)
+    e32 = nerr(ref32, ref64)
+    # the kernel should sit at the fp32 noise floor, not merely under the gate
+    assert e64 <= max(10 * e32, 2e-5), (e64, e32)
+
+
+def test_nonunit_frequencies():
+    sd = syn.make_state_dict(seed=9, w0=2.0)
+    m = make_model(sd, w0=2.0, w0_initial=10.0, act="morlet")
+    mods = syn.make_mods(6, 5, 4, 256)
+    out = m.forward_mods(mods)
+    ref = orc.siren_forward(sd, mods, num_layers=5, w0=2.0, w0_initial=10.0, activation="morlet", dtype=np.float64)
+    check(out.reshape(4, -1), ref)
+
+
+def test_empty_batch_and_errors():
+    sd = syn.make_state_dict(seed=7)
+    m = make_model(sd)
+    assert m.forward_mods(np.zeros((5, 0, 256), np.float32)).shape == (0, 24, 24)
+    assert m(np.zeros((0, 32, 32), np.float32)).shape == (0, 24, 24)
+    with pytest.raises(ValueError):
+        m.forward_mods(np.zeros((4, 2, 256), np.float32))
+    with pytest.raises(ValueError):
+        m(np.zeros((2, 24, 24), np.float32))
+    bad = dict(sd)
+    bad["net.layers.1.weight"] = np.zeros((256, 255), np.float32)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        m.load_state_dict(bad)
+    bad = dict(sd)
+    del bad["net.last_layer.bias"]
+    with pytest.raises(RuntimeError, match="Missing key"):
+        m.load_state_dict(bad)
+    with pytest.raises(ValueError):
+        ModulatedSiren(dim_in=3, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda", activation="sine")
+
+
+def test_torch_device_tensors_roundtrip():
+    import torch
+
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = make_model(sd)
+    tiles = np.random.default_rng(1).random((5, 32, 32), dtype=np.float32)
+    ref = m(tiles)
+    t = torch.from_numpy(tiles).cuda()
+    out = m(t)
+    assert out.is_cuda and out.shape == (5, 24, 24)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    out_cpu = m(torch.from_numpy(tiles))
+    assert not out_cpu.is_cuda and np.array_equal(out_cpu.numpy(), ref)
+
+
+def test_linearity_free_property_full_size():
+    """Size-independent property at config-2 size: patches are independent, so evaluating a batch
+    equals evaluating any split of it, and permuting patches permutes outputs (bit-exact)."""
+    sd = syn.make_state_dict(seed=7)
+    m = make_model(sd)
+    mods = syn.make_mods(77, 5, 400, 256)
+    full = m.forward_mods(mods)
+    a = m.forward_mods(mods[:, :150])
+    b = m.forward_mods(mods[:, 150:])
+    assert np.array_equal(full, np.concatenate([a, b], 0))
+    perm = np.random.default_rng(0).permutation(400)
+    assert np.array_equal(m.forward_mods(mods[:, perm]), full[perm])
+    assert np.abs(full).max() <= 1.0

@@ -118,3 +118,17 @@ def test_slice_reconstruction():
     assert rec.shape == g["image"].shape[1:]
     assert len(g["black"]) > 0
     assert nerr(rec, g["image"][0]) < 5e-5
+
+
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_torch_twin_matches_reference_fixture(act):
+    """The torch-CPU timing twin (bench.py's cpu_baseline) computes the same function."""
+    import torch
+
+    from oracle import torch_twin as tw
+
+    g = load_golden(f"forward_trained_{act}.npz")
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    tiles = np.random.default_rng(42).random((8, 32, 32), dtype=np.float32)
+    out = tw.forward_tiles(tw.to_tensors(sd), torch.from_numpy(tiles), num_layers=5, activation=act).numpy()
+    assert nerr(out, g["out"]) < 5e-5
