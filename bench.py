@@ -44,17 +44,34 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cores() -> int:
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota and by
+    the GPU box's per-GPU CPU share (16) -- oversubscribing MKL with 256 threads on a 16-core share
+    is ~15x slower than using the share."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit():
+        n = min(n, int(env))
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(sd, tiles, activation, budget_s):
     """The torch-CPU twin (oracle/torch_twin.py, "port") timed on this box's host cores."""
     import torch
 
     from oracle import torch_twin as tw
 
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = effective_cores()
     torch.set_num_threads(cores)
     t = tw.to_tensors(sd)
     x = torch.from_numpy(tiles)

@@ -108,6 +108,7 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
+        _init_torch_runtime_first()
         if not os.path.exists(LIB_PATH):
             raise MsirenError(
                 f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
@@ -121,6 +122,24 @@ def load():
             raise MsirenError(f"libmsiren ABI {lib.msiren_abi_version()} != binding {ABI_VERSION}")
         _lib = lib
         return lib
+
+
+def _init_torch_runtime_first():
+    """PyTorch-ROCm wheels bundle their own HIP/HSA runtime (soname ``libamdhip64.so``) next to the
+    system one this library links (``libamdhip64.so.7``).  Both can live in one process, but only if
+    torch's is initialised first; initialising it after ours makes ``torch.cuda`` report no GPUs.
+    So: if the host program has already imported torch, let it bring its runtime up before we dlopen
+    ours.  Nothing is imported here -- a torch-free host is unaffected."""
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is None:
+        return
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 def last_error() -> str:

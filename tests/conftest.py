@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # GPU tests hand torch device tensors to libmsiren: torch's bundled HIP runtime has to come up
+    # before the system one libmsiren links (mri_inr_amd/_lib.py:_init_torch_runtime_first)
+    if any(it.get_closest_marker("gpu") for it in items):
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
