@@ -171,6 +171,11 @@ MSIREN_API int msiren_device_count(int32_t* count);
 /* Algorithmic FLOPs per coordinate for the handle's configuration: 2*2*H + (L-1)*2*H*H + 2*H. */
 MSIREN_API int msiren_flops_per_coord(msiren_handle h, double* flops);
 MSIREN_API int msiren_abi_version(void);
+/* Diagnostic (H=256, sine only): runs a stamped build of the trunk kernel once and returns, per
+ * workgroup, 32 uint64: [0] HW_ID, [1] LDS_ALLOC, [2] XCC_ID, [3] s_memrealtime at start,
+ * [4..] s_memtime at each phase boundary.  Never used by the forward entry points. */
+MSIREN_API int msiren_trunk_timeline(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev,
+                                     uint64_t* stamps_host);
 
 #ifdef __cplusplus
 }

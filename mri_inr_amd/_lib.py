@@ -81,6 +81,7 @@ PROTOTYPES = {
     "msiren_profile_read": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "msiren_device_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_uint64)]),
     "msiren_flops_per_coord": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "msiren_trunk_timeline": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
 }
 
 _lib = None

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -310,7 +311,7 @@ int pack_fold_weights(msiren_ctx* h) {
 // ---- launches ---------------------------------------------------------------------------------
 template <int HP>
 int launch_trunk_hp(msiren_ctx* h, const msiren::TrunkParams& p, int grid) {
-    const size_t lds = (size_t)HP * 256;
+    const size_t lds = (size_t)HP * 256 + (size_t)HP * 16;  // X image + layer-0 rows
     const int act = h->cfg.activation, res = h->cfg.residual;
 #define MSIREN_LAUNCH(A, R)                                                                        \
     do {                                                                                           \
@@ -329,6 +330,27 @@ int launch_trunk_hp(msiren_ctx* h, const msiren::TrunkParams& p, int grid) {
     return 0;
 }
 
+msiren::TrunkParams make_trunk_params(msiren_ctx* h, const float* mods, int stride, int64_t B, float* out_dev) {
+    msiren::TrunkParams p{};
+    p.grid = h->d_grid;
+    p.l0 = h->d_l0;
+    p.wp = h->d_wp;
+    p.bias = h->d_bias;
+    p.wout = h->d_wout;
+    p.mods = mods;
+    p.out = out_dev;
+    p.bout = h->bout;
+    p.cg0 = h->cg0;
+    p.cg = h->cg;
+    p.B = (int)B;
+    p.P = h->P;
+    p.L = h->L;
+    p.mod_stride = stride;
+    p.chunks = (h->P + 63) / 64;
+    p.stamps = nullptr;
+    return p;
+}
+
 int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     if (B == 0) return 0;
     const int chunks = (h->P + 63) / 64;
@@ -345,22 +367,7 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
         mods = (const float*)h->ws_modpad.p;
         stride = h->HP;
     }
-    msiren::TrunkParams p{};
-    p.grid = h->d_grid;
-    p.l0 = h->d_l0;
-    p.wp = h->d_wp;
-    p.bias = h->d_bias;
-    p.wout = h->d_wout;
-    p.mods = mods;
-    p.out = out_dev;
-    p.bout = h->bout;
-    p.cg0 = h->cg0;
-    p.cg = h->cg;
-    p.B = (int)B;
-    p.P = h->P;
-    p.L = h->L;
-    p.mod_stride = stride;
-    p.chunks = chunks;
+    msiren::TrunkParams p = make_trunk_params(h, mods, stride, B, out_dev);
     const int grid = (int)(B * chunks);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -814,6 +821,27 @@ int msiren_device_info(msiren_handle h, char* name256, int32_t* cus, int32_t* mh
     if (cus) *cus = prop.multiProcessorCount;
     if (mhz) *mhz = prop.clockRate / 1000;
     if (hbm) *hbm = (uint64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+int msiren_trunk_timeline(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev, uint64_t* stamps_host) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (h->HP != 256 || h->cfg.activation != MSIREN_ACT_SINE || h->cfg.residual || h->H != 256)
+        return fail(MSIREN_E_INVALID, "the timeline diagnostic is built for H=256, sine, non-residual only");
+    if (B <= 0 || !mods_dev || !out_dev || !stamps_host) return fail(MSIREN_E_INVALID, "bad arguments");
+    const int chunks = (h->P + 63) / 64;
+    const int grid = (int)(B * chunks);
+    DevBuf st;
+    if ((rc = ensure(h, st, (size_t)grid * 32 * sizeof(uint64_t)))) return rc;
+    HIPCHK(hipMemsetAsync(st.p, 0, (size_t)grid * 32 * sizeof(uint64_t), h->stream));
+    msiren::TrunkParams p = make_trunk_params(h, mods_dev, h->H, B, out_dev);
+    p.stamps = (unsigned long long*)st.p;
+    hipLaunchKernelGGL((msiren::siren_trunk_f32_kernel<256, 0, 0, 1>), dim3(grid), dim3(256), 256 * 256 + 256 * 16, h->stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(stamps_host, st.p, (size_t)grid * 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(st.p));
     return 0;
 }
 

@@ -42,6 +42,7 @@ struct TrunkParams {
     float bout;          // scaled
     float cg0, cg;       // Morlet Gaussian constants for layer 0 / hidden layers
     int B, P, L, mod_stride, chunks;
+    unsigned long long* stamps;  // diagnostic build only: [grid][32] s_memtime stamps
 };
 
 // sin(2*pi*r): explicit round-to-nearest reduction (exact in fp32), then the hardware sine.
@@ -59,14 +60,17 @@ __device__ __forceinline__ float activate(float r, float cg) {
     }
 }
 
-template <int HP, int ACT, int RES>
+// DBG = 1 is a separate diagnostic instantiation (msiren_trunk_timeline): wave 0 of every workgroup
+// stamps s_memtime at each phase boundary into p.stamps; the shipped kernel (DBG = 0) has no stamps.
+template <int HP, int ACT, int RES, int DBG = 0>
 __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kernel(TrunkParams p) {
     constexpr int TT = HP / 128;  // 32-feature tiles per wave
-    constexpr int QN = HP / 8;    // k-iterations of 8
+    constexpr int QN = HP / 8;    // k-blocks of 8 per layer (16*TT/2 MFMAs each)
     constexpr int KG = HP / 4;    // k-groups of 4 (rows of the X image)
     static_assert(HP % 128 == 0, "hidden width is padded to a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    f32x4* X = reinterpret_cast<f32x4*>(lds);  // X[kg*64 + coord]
+    f32x4* X = reinterpret_cast<f32x4*>(lds);    // X[kg*64 + coord]              HP*256 B
+    f32x4* P0 = X + KG * 64;                     // layer-0 rows {wx, wy, b, mod} HP*16 B
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -76,40 +80,92 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
     const int b = blockIdx.x / p.chunks;
     const int ch = blockIdx.x - b * p.chunks;
     const int L = p.L;
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if constexpr (DBG) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (tid == 0 && nstamp < 28) p.stamps[(size_t)blockIdx.x * 32 + 4 + nstamp] = t;
+            ++nstamp;
+        }
+    };
+    if constexpr (DBG) {
+        if (tid == 0) {
+            unsigned hwid, ldsa, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(ldsa));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            p.stamps[(size_t)blockIdx.x * 32 + 0] = hwid;
+            p.stamps[(size_t)blockIdx.x * 32 + 1] = ldsa;
+            p.stamps[(size_t)blockIdx.x * 32 + 2] = xcc;
+            p.stamps[(size_t)blockIdx.x * 32 + 3] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+    stamp();  // 0: start
+
+    // ---------------- weight stream: a ring of 4 register stages, 3 k-blocks ahead --------------
+    // Block s of the stream is k-block (s % QN) of hidden layer 1 + s / QN.  The ring runs across
+    // layer boundaries: while a layer's epilogue executes, the next layer's first three blocks are
+    // already in flight.  A lone wave on a SIMD (its partner workgroup in an epilogue or at a
+    // barrier) issues 16*TT/2 MFMAs per block back to back, so the distance has to cover the L2
+    // latency at the FULL matrix rate -- one block ahead (~1000 cycles) does not.
+    const int nblk = (L - 1) * QN;
+    const f32x4* wbase = reinterpret_cast<const f32x4*>(p.wp) + lane;
+    auto loadA = [&](f32x4(&a)[TT], int s) {
+        s = s < nblk ? s : nblk - 1;  // past the end: harmless re-load of the last block
+        const int l1 = s / QN, q = s - l1 * QN;
+        const f32x4* ptr = wbase + (((size_t)l1 * 4 + wave) * QN + q) * (TT * 64);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) a[tt] = ptr[tt * 64];
+    };
+    f32x4 a0[TT], a1[TT], a2[TT], a3[TT];
+    if (L > 1) {
+        loadA(a0, 0);
+        loadA(a1, 1);
+        loadA(a2, 2);
+    }
 
     // ---------------- layer 0: K = 2, straight into the X image --------------------------------
     {
+        // per-feature rows {w_row, w_col, bias, mod0} staged once, then broadcast-read from LDS
+        const float* mod0 = p.mods + (size_t)b * p.mod_stride;
+        const f32x4* l0 = reinterpret_cast<const f32x4*>(p.l0);
+        for (int f = tid; f < HP; f += 256) {
+            f32x4 w = l0[f];
+            w[3] = mod0[f];
+            P0[f] = w;
+        }
         int pc = ch * 64 + lane;
         pc = pc < p.P ? pc : p.P - 1;
         const float2 xy = reinterpret_cast<const float2*>(p.grid)[pc];
-        const float* mod0 = p.mods + (size_t)b * p.mod_stride;
-        const f32x4* l0 = reinterpret_cast<const f32x4*>(p.l0);
-#pragma unroll 2
+        __syncthreads();
+#pragma unroll 4
         for (int i = 0; i < KG / 4; ++i) {
             const int kg = wave * (KG / 4) + i;
-            const f32x4 m = *reinterpret_cast<const f32x4*>(mod0 + 4 * kg);
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const f32x4 w = l0[4 * kg + e];
+                const f32x4 w = P0[4 * kg + e];
                 const float r = __builtin_fmaf(xy.y, w.y, __builtin_fmaf(xy.x, w.x, w.z));
-                v[e] = activate<ACT>(r, p.cg0) * m[e];
+                v[e] = activate<ACT>(r, p.cg0) * w[3];
             }
             X[kg * 64 + lane] = v;
         }
     }
     __syncthreads();
+    stamp();  // 1: layer 0 done
 
     // ---------------- hidden layers 1..L-1 on the matrix cores ---------------------------------
     const int fwave = wave * (32 * TT);  // first feature owned by this wave
     float part[2] = {0.f, 0.f};          // last_layer partial sums (used on the final hidden layer)
 
     for (int l = 1; l < L; ++l) {
-        const f32x4* wA = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)(l - 1) * 4 + wave) * (QN * TT * 64) + lane;
         const float* bl = p.bias + (size_t)(l - 1) * HP;
         const float* ml = p.mods + ((size_t)l * p.B + b) * p.mod_stride;
+        const bool last = (l == L - 1);
 
-        // per-feature constants of this wave's rows: issued now, consumed in the epilogue
+        // per-feature constants of this wave's rows: issued now, consumed in the epilogue.
+        // On the final hidden layer the modulation is pre-multiplied by last_layer's weight:
+        // out = sum_f act_f * (mod_f * wout_f)  (the residual variant needs them separately).
         f32x4 bias_r[TT][4], mod_r[TT][4];
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
@@ -119,6 +175,13 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
                 bias_r[tt][g] = *reinterpret_cast<const f32x4*>(bl + fo);
                 mod_r[tt][g] = *reinterpret_cast<const f32x4*>(ml + fo);
             }
+        if (!RES && last) {
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    mod_r[tt][g] *= *reinterpret_cast<const f32x4*>(p.wout + fwave + 32 * tt + 8 * g + 4 * half);
+        }
 
         f32x16 acc[TT][2];
 #pragma unroll
@@ -129,13 +192,11 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
                 for (int r = 0; r < 16; ++r) acc[tt][jc][r] = 0.f;
 
         const f32x4* xB = X + half * 64 + c32;  // + (2q)*64 + 32*jc
-
-        f32x4 a0[TT], a1[TT], b0[2], b1[2];
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) a0[tt] = wA[tt * 64];
-        b0[0] = xB[0];
-        b0[1] = xB[32];
-
+        auto loadB = [&](f32x4(&bb)[2], int q) {
+            q = q < QN ? q : QN - 1;
+            bb[0] = xB[(2 * q) * 64];
+            bb[1] = xB[(2 * q) * 64 + 32];
+        };
         auto mma = [&](const f32x4(&a)[TT], const f32x4(&bb)[2]) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -146,33 +207,41 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
                         acc[tt][jc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt][j], bb[jc][j], acc[tt][jc], 0, 0, 0);
         };
 
-        // Software pipeline, distance one k-step (16 MFMAs ~ 1024 cycles): the loads of step q+1 are
-        // issued before the MFMAs of step q.  sched_barrier pins that order -- without it hipcc sinks
-        // every load down to its first use and exposes the L2 latency once per 8 MFMAs.
+        f32x4 b0[2], b1[2];
+        loadB(b0, 0);
+        const int sb = (l - 1) * QN;
+        // sched_barrier pins "issue the loads of later blocks, then this block's MFMAs": left alone,
+        // hipcc sinks every load down to its first use and exposes the L2 latency per block.
 #pragma nounroll
-        for (int q = 0; q < QN; q += 2) {
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) a1[tt] = wA[((q + 1) * TT + tt) * 64];
-            b1[0] = xB[(2 * (q + 1)) * 64];
-            b1[1] = xB[(2 * (q + 1)) * 64 + 32];
+        for (int q = 0; q < QN; q += 4) {
+            loadA(a3, sb + q + 3);
+            loadB(b1, q + 1);
             __builtin_amdgcn_sched_barrier(0);
             mma(a0, b0);
             __builtin_amdgcn_sched_barrier(0);
-            if (q + 2 < QN) {
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt) a0[tt] = wA[((q + 2) * TT + tt) * 64];
-                b0[0] = xB[(2 * (q + 2)) * 64];
-                b0[1] = xB[(2 * (q + 2)) * 64 + 32];
-            }
+            loadA(a0, sb + q + 4);
+            loadB(b0, q + 2);
             __builtin_amdgcn_sched_barrier(0);
             mma(a1, b1);
             __builtin_amdgcn_sched_barrier(0);
+            loadA(a1, sb + q + 5);
+            loadB(b1, q + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a2, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            loadA(a2, sb + q + 6);
+            loadB(b0, q + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a3, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
+        stamp();  // K loop done (this wave)
         __syncthreads();  // every wave has finished reading X: rows may now be overwritten
+        stamp();  // barrier passed
 
         const int kgw = wave * (8 * TT);
-        if (l < L - 1) {
+        if (!last) {
             // epilogue: bias -> activation -> modulation, back into this wave's rows of the X image
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt)
@@ -191,13 +260,15 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
                         X[xi] = v;
                     }
             __syncthreads();
+            stamp();  // epilogue + barrier done
         } else {
             // final hidden layer: its output feeds last_layer's dot product straight from registers
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 wo = *reinterpret_cast<const f32x4*>(p.wout + fwave + 32 * tt + 8 * g + 4 * half);
+                    f32x4 wo;
+                    if constexpr (RES) wo = *reinterpret_cast<const f32x4*>(p.wout + fwave + 32 * tt + 8 * g + 4 * half);
 #pragma unroll
                     for (int jc = 0; jc < 2; ++jc) {
                         f32x4 v;
@@ -206,8 +277,11 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
                             const float r = acc[tt][jc][4 * g + e] + bias_r[tt][g][e];
                             v[e] = activate<ACT>(r, p.cg) * mod_r[tt][g][e];
                         }
-                        if constexpr (RES) v += X[(kgw + 8 * tt + 2 * g + half) * 64 + 32 * jc + c32];
-                        part[jc] += v[0] * wo[0] + v[1] * wo[1] + v[2] * wo[2] + v[3] * wo[3];
+                        if constexpr (RES) {
+                            v += X[(kgw + 8 * tt + 2 * g + half) * 64 + 32 * jc + c32];
+                            v *= wo;
+                        }
+                        part[jc] += (v[0] + v[1]) + (v[2] + v[3]);
                     }
                 }
         }
@@ -242,6 +316,10 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
         const float s = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid] + p.bout;
         const int pc = ch * 64 + tid;
         if (pc < p.P) p.out[(size_t)b * p.P + pc] = sin_rev(s);
+    }
+    stamp();  // end
+    if constexpr (DBG) {
+        if (tid == 0) p.stamps[(size_t)blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
