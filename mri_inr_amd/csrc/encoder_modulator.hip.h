@@ -155,4 +155,57 @@ __global__ __launch_bounds__(256) void modulator_layer_kernel(ModulatorLayerPara
     }
 }
 
+
+// ---- modulator layer on the matrix cores ---------------------------------------------------------
+// Same contract as modulator_layer_kernel, for H, Z, Kh all multiples of 16.  One workgroup = one
+// 16 x 16 output tile (16 patches x 16 features); its 4 waves split K four ways and each runs a chain
+// of v_mfma_f32_16x16x4_f32 (exact fp32) on float4 fragments read straight from the row-major
+// operands: lane l holds in[row l&15][k0 + 4(l>>4) + j] and W[feature l&15][k0 + 4(l>>4) + j], j = 0..3,
+// so one pair of 16-byte loads feeds 4 MFMAs.  `w` is the nn.Linear weight as stored, (H, Kh+Z).
+typedef float mod_f32x4 __attribute__((ext_vector_type(4)));
+
+struct ModulatorMfmaParams {
+    const float* w;      // (H, Kh + Z) row-major
+    const float* bias;   // (H)
+    const float* hprev;  // (B, H) or nullptr
+    const float* z;      // (B, Z)
+    float* out;          // (B, H)
+    int B, H, Z, Kh;
+};
+
+__global__ __launch_bounds__(256) void modulator_layer_mfma_kernel(ModulatorMfmaParams p) {
+    __shared__ float red[4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * 16, f0 = blockIdx.y * 16;
+    const int row = min(r0 + (lane & 15), p.B - 1);
+    const int f = f0 + (lane & 15);
+    const int kq = lane >> 4;
+    const int K = p.Kh + p.Z;
+    const int nb = K / 16;
+    const int b_lo = (nb * wave) / 4, b_hi = (nb * (wave + 1)) / 4;
+    const float* wrow = p.w + (size_t)f * K + 4 * kq;
+    const float* hrow = p.hprev ? p.hprev + (size_t)row * p.H + 4 * kq : nullptr;
+    const float* zrow = p.z + (size_t)row * p.Z + 4 * kq;
+    mod_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int blk = b_lo; blk < b_hi; ++blk) {
+        const int k0 = blk * 16;
+        const mod_f32x4 a = *reinterpret_cast<const mod_f32x4*>(k0 < p.Kh ? hrow + k0 : zrow + (k0 - p.Kh));
+        const mod_f32x4 b = *reinterpret_cast<const mod_f32x4*>(wrow + k0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+    }
+    // D layout: col = lane & 15 (feature), row = 4 * (lane >> 4) + reg (patch)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][lane & 15] = acc0[r] + acc1[r];
+    __syncthreads();
+    const int rr = tid >> 4, cc = tid & 15;
+    if (r0 + rr < p.B) {
+        const float s = red[0][rr][cc] + red[1][rr][cc] + red[2][rr][cc] + red[3][rr][cc] + p.bias[f0 + cc];
+        p.out[(size_t)(r0 + rr) * p.H + f0 + cc] = s > 0.f ? s : 0.f;
+    }
+}
+
 }  // namespace msiren

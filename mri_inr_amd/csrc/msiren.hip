@@ -61,7 +61,7 @@ struct msiren_ctx {
     float *d_grid = nullptr, *d_l0 = nullptr, *d_wp = nullptr, *d_bias = nullptr, *d_wout = nullptr;
     float bout = 0.f, cg0 = 0.f, cg = 0.f;
     // modulator: transposed weights so that consecutive threads read consecutive outputs
-    float *d_modw = nullptr, *d_modb = nullptr;
+    float *d_modw = nullptr, *d_modb = nullptr, *d_modw_rm = nullptr;  // transposed / as stored (row-major)
     // encoder
     float *d_encw = nullptr;
     msiren::EncoderParams enc{};
@@ -234,8 +234,16 @@ int pack_modulator(msiren_ctx* h) {
         for (int f = 0; f < H; ++f) bb[(size_t)l * H + f] = (*b)[f];
         off += (size_t)K * H;
     }
+    std::vector<float> rm(total);
+    off = 0;
+    for (int l = 0; l < L; ++l) {
+        const auto* w = get(h, "modulator.layers." + std::to_string(l) + ".0.weight");
+        std::copy(w->begin(), w->end(), rm.begin() + off);
+        off += w->size();
+    }
     int rc;
     if ((rc = upload(&h->d_modw, wt))) return rc;
+    if ((rc = upload(&h->d_modw_rm, rm))) return rc;
     if ((rc = upload(&h->d_modb, bb))) return rc;
     return 0;
 }
@@ -400,6 +408,26 @@ int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_d
     if (B == 0) return 0;
     if (!h->have_modulator) return fail(MSIREN_E_STATE, "modulator.* weights were not loaded");
     size_t off = 0;
+    const bool mfma_ok = (h->H % 16 == 0) && (h->Z % 16 == 0);
+    for (int l = 0; l < h->L && mfma_ok; ++l) {
+        const int Kh = (l == 0 ? 0 : h->H);
+        msiren::ModulatorMfmaParams mp{};
+        mp.w = h->d_modw_rm + off;
+        mp.bias = h->d_modb + (size_t)l * h->H;
+        mp.hprev = l == 0 ? nullptr : mods_dev + (size_t)(l - 1) * B * h->H;
+        mp.z = z_dev;
+        mp.out = mods_dev + (size_t)l * B * h->H;
+        mp.B = (int)B;
+        mp.H = h->H;
+        mp.Z = h->Z;
+        mp.Kh = Kh;
+        dim3 grid((unsigned)((B + 15) / 16), (unsigned)(h->H / 16));
+        hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, grid, dim3(256), 0, h->stream, mp);
+        HIPCHK(hipGetLastError());
+        off += (size_t)(Kh + h->Z) * h->H;
+    }
+    if (mfma_ok) return 0;
+    off = 0;
     for (int l = 0; l < h->L; ++l) {
         const int Kh = (l == 0 ? 0 : h->H);
         msiren::ModulatorLayerParams mp{};
@@ -521,7 +549,7 @@ int msiren_destroy(msiren_handle h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    float* ptrs[] = {h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modb, h->d_encw, h->d_foldw};
+    float* ptrs[] = {h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&h->ws_mods, &h->ws_modpad, &h->ws_out, &h->ws_latent, &h->ws_tiles, &h->ws_in, &h->ws_patches, &h->ws_keep, &h->ws_rec, &h->ws_img};

@@ -186,3 +186,26 @@ def test_linearity_free_property_full_size():
     perm = np.random.default_rng(0).permutation(400)
     assert np.array_equal(m.forward_mods(mods[:, perm]), full[perm])
     assert np.abs(full).max() <= 1.0
+
+
+@pytest.mark.parametrize("H,Z,L,B", [(256, 256, 5, 400), (256, 256, 5, 3), (64, 48, 3, 17), (100, 24, 2, 5)])
+def test_modulator_kernels_vs_oracle(H, Z, L, B):
+    """latent -> mods on the device (MFMA kernel when H, Z are multiples of 16, VALU kernel otherwise)."""
+    from mri_inr_amd import _lib
+
+    sd = syn.make_state_dict(seed=13, dim_hidden=H, num_layers=L, latent_dim=Z, siren_patch_size=8,
+                             modulator_bias_center=0.3, with_encoder=False)
+    m = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=8, device="cuda", activation="sine")
+    m.load_state_dict(sd, strict=False)
+    m.to("cuda")
+    z = np.random.default_rng(2).standard_normal((B, Z)).astype(np.float32)
+    out = np.empty((B, 8, 8), np.float32)
+    mods = np.empty((L, B, H), np.float32)
+    _lib.check(m._lib.msiren_forward_latent(m._h, z.ctypes.data, B, out.ctypes.data, mods.ctypes.data))
+    ref_mods = orc.modulator_forward(sd, z, num_layers=L, dtype=np.float64)
+    assert nerr(mods, ref_mods) < 1e-5
+    assert (mods >= 0).all()
+    ref = orc.siren_forward(sd, ref_mods, num_layers=L, siren_patch_size=8, dtype=np.float64)
+    check(out.reshape(B, -1), ref)
