@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Evaluation driver with the reference's command line and artefacts, on the MI355X path.
+
+    python test_mod_siren.py --config configuration/eval_sine.yaml
+
+Mirrors test_mod_siren.py of the reference (:78-262): build ``ModulatedSiren`` from ``config.model``,
+load ``config.testing.model_path``, reconstruct ``config.data.metric_samples`` slices and write
+``metrics_error.csv`` + ``metrics_summary.txt`` (same formats, :38-75, :236-247) under
+``{output_dir}/{output_name}/test``.  Differences, all forced by the container:
+  * the slice pipeline (tiling -> black filter -> model -> weighted fold; error.py:231-249) runs on the
+    GPU inside ``model.reconstruct`` instead of torch ops around ``model(tiles)``;
+  * ``data.dataset: synthetic`` / ``testing.model_path: synthetic`` select seeded synthetic slices and
+    weights (no fastMRI data or checkpoints here); a directory of ``*.npy`` slice pairs
+    (``<name>_fully.npy`` / ``<name>_under.npy``) is read otherwise;
+  * plots (seaborn/matplotlib box and density plots) are not produced.
+"""
+
+from __future__ import annotations
+
+import glob
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from mri_inr_amd import ModulatedSiren, load_configuration, model_kwargs, synthetic  # noqa: E402
+from mri_inr_amd.configuration import parse_args  # noqa: E402
+from mri_inr_amd.metrics import calculate_nrmse, calculate_psnr, calculate_ssim  # noqa: E402
+from mri_inr_amd.weights import load_checkpoint  # noqa: E402
+
+
+def save_metrics_summary(psnr_values, ssim_values, nrmse_values, output_dir):
+    with open(os.path.join(output_dir, "metrics_summary.txt"), "w") as f:
+        for metric, v in (("PSNR", psnr_values), ("SSIM", ssim_values), ("NRMSE", nrmse_values)):
+            f.write(f"{metric}:\n")
+            for stat, fn in (("mean", np.mean), ("std", np.std), ("min", np.min), ("max", np.max)):
+                f.write(f"  {stat}: {fn(v)}\n")
+            f.write("\n")
+
+
+def samples(config):
+    """Yield (fully_sampled, undersampled, filename) float32 (H, W) pairs."""
+    n = config.data.metric_samples
+    if config.data.dataset == "synthetic":
+        for k in range(n or 8):
+            full = synthetic.make_slice(k, brain_mask=True)
+            # a crude stand-in for undersampling artefacts: horizontal blur (no fastmri mask maths here)
+            under = (full + np.roll(full, 1, 1) + np.roll(full, -1, 1)) / np.float32(3)
+            yield full, under.astype(np.float32), f"synthetic_{k:04d}"
+        return
+    files = sorted(glob.glob(os.path.join(config.data.dataset, "*_fully.npy")))
+    for path in files[: (n or len(files))]:
+        name = os.path.basename(path)[: -len("_fully.npy")]
+        yield (np.load(path).astype(np.float32), np.load(path.replace("_fully", "_under")).astype(np.float32), name)
+
+
+def test_mod_siren(config):
+    print("Testing the modulated SIREN...")
+    output_dir = f"{config.testing.output_dir}/{config.testing.output_name}/test"
+    os.makedirs(output_dir, exist_ok=True)
+    model = ModulatedSiren(**model_kwargs(config, device="cuda", modulate=True))
+    if config.testing.model_path == "synthetic":
+        sd = synthetic.make_state_dict(seed=7, dim_hidden=config.model.dim_hidden, num_layers=config.model.num_layers,
+                                       latent_dim=config.model.latent_dim, w0=config.model.w0,
+                                       siren_patch_size=config.model.siren_patch_size,
+                                       use_bias=config.model.use_bias, trained_like=True)
+    else:
+        sd = load_checkpoint(config.testing.model_path)
+    model.load_state_dict(sd)
+    model.to("cuda")
+    model.eval()
+
+    names, psnrs, ssims, nrmses = [], [], [], []
+    t_gpu = 0.0
+    print("Evaluating metric samples ...")
+    for i, (full, under, name) in enumerate(samples(config)):
+        print(f"Processing metric sample {i + 1}...")
+        t0 = time.perf_counter()
+        rec = model.reconstruct(under)
+        t_gpu += time.perf_counter() - t0
+        ref = full[: rec.shape[0], : rec.shape[1]]
+        if ref.shape != rec.shape:  # the reconstruction is padded up to a multiple of inner_patch_size
+            ref = np.pad(ref, ((0, rec.shape[0] - ref.shape[0]), (0, rec.shape[1] - ref.shape[1])), mode="reflect")
+        names.append(name)
+        psnrs.append(calculate_psnr(ref, rec))
+        ssims.append(calculate_ssim(ref, rec))
+        nrmses.append(calculate_nrmse(ref, rec))
+    with open(os.path.join(output_dir, "metrics_error.csv"), "w") as f:
+        f.write("FILENAME,PSNR,SSIM,NRMSE\n")
+        for row in zip(names, psnrs, ssims, nrmses):
+            f.write(",".join(str(v) for v in row) + "\n")
+    save_metrics_summary(psnrs, ssims, nrmses, output_dir)
+    px = sum(1 for _ in names) * 320 * 320
+    print(f"{len(names)} slices reconstructed in {t_gpu:.3f} s host wall (incl. H2D/D2H) -> {output_dir}")
+    return output_dir
+
+
+if __name__ == "__main__":
+    args = parse_args()
+    test_mod_siren(load_configuration(args.config, testing=True))
