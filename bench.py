@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--slices", type=int, default=1, help="320x320 slices per GPU per step")
     ap.add_argument("--activation", default="sine", choices=["sine", "morlet"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--check", action="store_true", help="also verify one batch against the oracle")
@@ -119,7 +120,7 @@ def main():
     model = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
                            use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
                            outer_patch_size=32, inner_patch_size=16, siren_patch_size=24,
-                           device=f"cuda:{local_rank}", activation=args.activation)
+                           device=f"cuda:{local_rank}", activation=args.activation, precision=args.precision)
     model.load_state_dict(sd)
     model.to(f"cuda:{local_rank}").eval()
     lib, h = model._lib, model._h

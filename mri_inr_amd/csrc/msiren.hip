@@ -18,6 +18,7 @@
 
 #include "../../include/msiren.h"
 #include "encoder_modulator.hip.h"
+#include "siren_trunk_f16x3.hip.h"
 #include "siren_trunk_f32.hip.h"
 #include "tiling.hip.h"
 
@@ -60,6 +61,12 @@ struct msiren_ctx {
     // trunk
     float *d_grid = nullptr, *d_l0 = nullptr, *d_wp = nullptr, *d_bias = nullptr, *d_wout = nullptr;
     float bout = 0.f, cg0 = 0.f, cg = 0.f;
+    // split-fp16 trunk (MSIREN_PREC_F16X3)
+    void* d_wp16 = nullptr;
+    float *d_bias16 = nullptr, *d_wout16 = nullptr;
+    float winv16[16] = {0};
+    bool f16x3_ready = false;
+    int num_cus = 256;
     // modulator: transposed weights so that consecutive threads read consecutive outputs
     float *d_modw = nullptr, *d_modb = nullptr, *d_modw_rm = nullptr;  // transposed / as stored (row-major)
     // encoder
@@ -215,6 +222,69 @@ int pack_trunk(msiren_ctx* h) {
     return 0;
 }
 
+// ---- split-fp16 trunk packing ------------------------------------------------------------------
+// Chunk (layer l, feature tile t) = [16 k-steps][hi|lo][64 lanes][8 x f16]; lane (r = lane&31, h = lane>>5),
+// element j of k-step s multiplies feature  kf = 32*(s>>1) + 16*(s&1) + 8*(j>>2) + 4*h + (j&3)  of the
+// previous layer -- the order in which the previous layer's accumulator registers hold them.
+// Weights are scaled by w0/2pi and by 2^e (e per layer, max|W| -> [8192, 16384)) before the split.
+uint16_t f32_to_f16_rne(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+float f16_to_f32(uint16_t u) {
+    _Float16 h;
+    std::memcpy(&h, &u, 2);
+    return (float)h;
+}
+
+int pack_trunk_f16x3(msiren_ctx* h) {
+    h->f16x3_ready = false;
+    const int H = h->H, L = h->L;
+    if (H != 256 || L < 2 || L > 17) return 0;
+    const double two_pi = 6.283185307179586476925286766559;
+    const double c = (double)h->cfg.w0 / two_pi;
+    std::vector<uint16_t> wp((size_t)(L - 1) * 8 * 16 * 2 * 64 * 8);
+    std::vector<float> bias((size_t)(L - 1) * 256, 0.f), wout(256, 0.f);
+    for (int l = 1; l < L; ++l) {
+        const std::vector<float>& w = *get(h, "net.layers." + std::to_string(l) + ".weight");
+        double mx = 0.0;
+        for (float v : w) mx = std::max(mx, std::fabs((double)v * c));
+        int e = 0;
+        if (mx > 0.0) e = (int)std::floor(std::log2(16384.0 / mx));
+        e = std::max(-14, std::min(e, 30));
+        const double sc = std::ldexp(c, e);
+        h->winv16[l - 1] = (float)std::ldexp(1.0, -e);
+        for (int t = 0; t < 8; ++t)
+            for (int s = 0; s < 16; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int f = 32 * t + (lane & 31);
+                        const int k = 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+                        const float ws = (float)((double)w[(size_t)f * H + k] * sc);
+                        const uint16_t hi = f32_to_f16_rne(ws);
+                        const uint16_t lo = f32_to_f16_rne(ws - f16_to_f32(hi));
+                        const size_t base = ((((size_t)(l - 1) * 8 + t) * 16 + s) * 2) * 64 * 8;
+                        wp[base + (size_t)lane * 8 + j] = hi;
+                        wp[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
+                    }
+        if (const auto* b = h->cfg.use_bias ? get(h, "net.layers." + std::to_string(l) + ".bias") : nullptr)
+            for (int f = 0; f < H; ++f) bias[(size_t)(l - 1) * 256 + f] = (float)((double)(*b)[f] * c);
+    }
+    const auto* Wo = get(h, "net.last_layer.weight");
+    for (int f = 0; f < H; ++f) wout[f] = (float)((double)(*Wo)[f] * c);
+    if (h->d_wp16) HIPCHK(hipFree(h->d_wp16));
+    h->d_wp16 = nullptr;
+    HIPCHK(hipMalloc(&h->d_wp16, wp.size() * 2));
+    HIPCHK(hipMemcpy(h->d_wp16, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = upload(&h->d_bias16, bias))) return rc;
+    if ((rc = upload(&h->d_wout16, wout))) return rc;
+    h->f16x3_ready = true;
+    return 0;
+}
+
 // ---- modulator / encoder packing ------------------------------------------------------------
 int pack_modulator(msiren_ctx* h) {
     const int H = h->H, Z = h->Z, L = h->L;
@@ -359,8 +429,72 @@ msiren::TrunkParams make_trunk_params(msiren_ctx* h, const float* mods, int stri
     return p;
 }
 
+template <int R>
+int launch_trunk_f16x3_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int grid) {
+    const int lds = msiren::F16Lds<R>::total(h->L);
+    auto k0 = msiren::siren_trunk_f16x3_kernel<0, R>;
+    auto k1 = msiren::siren_trunk_f16x3_kernel<1, R>;
+    const void* kp = h->cfg.activation == MSIREN_ACT_MORLET ? (const void*)k1 : (const void*)k0;
+    HIPCHK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (h->cfg.activation == MSIREN_ACT_MORLET)
+        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, h->stream, p);
+    else
+        hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, h->stream, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
+    msiren::TrunkF16Params p{};
+    p.grid = h->d_grid;
+    p.l0 = h->d_l0;
+    p.wp = (const _Float16*)h->d_wp16;
+    p.bias = h->d_bias16;
+    p.wout = h->d_wout16;
+    p.mods = mods_dev;
+    p.out = out_dev;
+    for (int i = 0; i < 16; ++i) p.winv[i] = h->winv16[i];
+    p.bout = h->bout;
+    p.cg0 = h->cg0;
+    p.cg = h->cg;
+    p.B = (int)B;
+    p.P = h->P;
+    p.L = h->L;
+    p.units_per_patch = (h->P + 31) / 32;
+    const int64_t units = B * p.units_per_patch;
+    if (units > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
+    p.total_units = (int)units;
+    const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
+    if (msiren::F16Lds<4>::total(h->L) <= 160 * 1024) return launch_trunk_f16x3_r<4>(h, p, grid);
+    return launch_trunk_f16x3_r<3>(h, p, grid);
+}
+
+bool use_f16x3(msiren_ctx* h) {
+    return h->cfg.precision == MSIREN_PREC_F16X3 && h->f16x3_ready && !h->cfg.residual &&
+           msiren::F16Lds<3>::total(h->L) <= 160 * 1024;
+}
+
 int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     if (B == 0) return 0;
+    if (use_f16x3(h)) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->profile) {
+            if (h->prof_used == h->prof_events.size()) {
+                hipEvent_t a, b2;
+                HIPCHK(hipEventCreate(&a));
+                HIPCHK(hipEventCreate(&b2));
+                h->prof_events.emplace_back(a, b2);
+            }
+            e0 = h->prof_events[h->prof_used].first;
+            e1 = h->prof_events[h->prof_used].second;
+            h->prof_used++;
+            HIPCHK(hipEventRecord(e0, h->stream));
+        }
+        int rc = launch_trunk_f16x3(h, mods_dev, B, out_dev);
+        if (rc) return rc;
+        if (h->profile) HIPCHK(hipEventRecord(e1, h->stream));
+        return 0;
+    }
     const int chunks = (h->P + 63) / 64;
     if (B * (int64_t)chunks > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     const float* mods = mods_dev;
@@ -513,7 +647,8 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (cfg->inner_patch_size < 1 || cfg->outer_patch_size < cfg->inner_patch_size)
         return fail(MSIREN_E_INVALID, "need outer_patch_size >= inner_patch_size >= 1");
     if (cfg->activation != MSIREN_ACT_SINE && cfg->activation != MSIREN_ACT_MORLET) return fail(MSIREN_E_INVALID, "unknown activation %d", cfg->activation);
-    if (cfg->precision != MSIREN_PREC_F32) return fail(MSIREN_E_INVALID, "precision %d is not available in this build (fp32 only)", cfg->precision);
+    if (cfg->precision != MSIREN_PREC_F32 && cfg->precision != MSIREN_PREC_F16X3)
+        return fail(MSIREN_E_INVALID, "precision %d is not available in this build (f32 = 0, f16x3 = 2)", cfg->precision);
     if (cfg->w0 == 0.f || cfg->w0_initial == 0.f) return fail(MSIREN_E_INVALID, "w0 and w0_initial must be non-zero");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -532,6 +667,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     h->P = h->S * h->S;
     h->O = cfg->outer_patch_size;
     h->I = cfg->inner_patch_size;
+    h->num_cus = prop.multiProcessorCount;
     declare_expected(h);
     hipError_t e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -549,7 +685,8 @@ int msiren_destroy(msiren_handle h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    float* ptrs[] = {h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
+    if (h->d_wp16) (void)hipFree(h->d_wp16);
+    float* ptrs[] = {h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&h->ws_mods, &h->ws_modpad, &h->ws_out, &h->ws_latent, &h->ws_tiles, &h->ws_in, &h->ws_patches, &h->ws_keep, &h->ws_rec, &h->ws_img};
@@ -582,6 +719,7 @@ int msiren_commit_weights(msiren_handle h) {
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     if ((rc = pack_trunk(h))) return rc;
+    if ((rc = pack_trunk_f16x3(h))) return rc;
     if ((rc = pack_fold_weights(h))) return rc;
     rc = pack_modulator(h);
     if (rc < 0) return rc;

@@ -209,3 +209,54 @@ def test_modulator_kernels_vs_oracle(H, Z, L, B):
     assert (mods >= 0).all()
     ref = orc.siren_forward(sd, ref_mods, num_layers=L, siren_patch_size=8, dtype=np.float64)
     check(out.reshape(B, -1), ref)
+
+
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_f16x3_trunk_vs_reference_fixtures(act):
+    """Split-fp16 trunk (3 x f16 MFMA per product, fp32 accumulate): same gate as the fp32 path."""
+    g = load_golden(f"trunk_{act}.npz")
+    sd = syn.make_state_dict(seed=7)
+    m = make_model(sd, act=act, precision="f16x3")
+    cases = {
+        "uniform_B1": syn.make_mods(31, 5, 1, 256),
+        "uniform_B64": syn.make_mods(32, 5, 64, 256),
+        "sparse_B16": syn.make_mods(33, 5, 16, 256, lo=0.0, hi=2.0, zero_fraction=0.5),
+        "modulator_B16": g["modulator_mods"],
+    }
+    for name, mods in cases.items():
+        out = m.forward_mods(mods)
+        check(out.reshape(out.shape[0], -1), g[name])
+
+
+@pytest.mark.parametrize("L,S,B", [(5, 24, 400), (5, 24, 7), (2, 24, 5), (3, 10, 9), (4, 24, 1030), (6, 8, 33)])
+def test_f16x3_trunk_vs_oracle_shapes(L, S, B):
+    sd = syn.make_state_dict(seed=4, num_layers=L, siren_patch_size=S, with_encoder=False)
+    sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
+    m = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=L, latent_dim=256, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=S, device="cuda", activation="sine",
+                       precision="f16x3")
+    m.load_state_dict(sd, strict=False)
+    m.to("cuda")
+    mods = syn.make_mods(5, L, B, 256)
+    out = m.forward_mods(mods)
+    ref64 = orc.siren_forward(sd, mods, num_layers=L, siren_patch_size=S, dtype=np.float64)
+    e64 = check(out.reshape(B, -1), ref64)
+    e32 = nerr(orc.siren_forward(sd, mods, num_layers=L, siren_patch_size=S), ref64)
+    assert e64 <= max(10 * e32, 2e-5), (e64, e32)
+    # determinism + batch-split equivariance (persistent grid: unit -> wave mapping changes with B)
+    assert np.array_equal(out, m.forward_mods(mods))
+    k = B // 3
+    if k:
+        assert np.array_equal(out[:k], m.forward_mods(mods[:, :k]))
+
+
+def test_f16x3_full_forward_matches_fp32_path():
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m32 = make_model(sd)
+    m16 = make_model(sd, precision="f16x3")
+    tiles = np.random.default_rng(3).random((50, 32, 32), dtype=np.float32)
+    a, b = m32(tiles), m16(tiles)
+    ref = orc.modulated_siren_forward(sd, tiles, num_layers=5, dtype=np.float64)
+    assert nerr(a, ref) < 1e-4 and nerr(b, ref) < 1e-4
+    assert nerr(b, a) < 5e-5
