@@ -68,6 +68,27 @@ __device__ __forceinline__ h8 pack_h8(fp16x2 a, fp16x2 b, fp16x2 c, fp16x2 d) {
     return __builtin_bit_cast(h8, u);
 }
 
+// Register-file placement.  The kernel keeps 256 registers of activations (this layer's and the next
+// layer's B operands) live for a whole layer; they only fit if they sit in the ACCUMULATOR half of the
+// unified 512-register file, which MFMA can read B from directly.  hipcc keeps builtin-MFMA operands
+// in arch VGPRs (and then spills ~300 of them), so the placement is pinned here: values are moved to
+// an "a"-class register once, when produced, and the MFMAs are issued through asm with "a" operands.
+__device__ __forceinline__ h8 to_acc_file(h8 v) {
+    h8 r;
+    asm("; activation fragment -> AGPR" : "=a"(r) : "0"(v));
+    return r;
+}
+// D = A*B (first k-step of a tile: C = 0) and D += A*B.  A (weights) and the accumulator in arch VGPRs,
+// B (activations) in AGPRs: 2 x 128 activation registers fill the accumulator half exactly.  Hazards hipcc would pad for the builtin are covered by construction:
+// every B fragment is written at least one scheduling group (>100 cycles) before its first use, and
+// an accumulator is read by VALU only in the NEXT tile, behind an s_barrier.
+__device__ __forceinline__ void mfma_f16_first(f32x16& d, const h8& a, const h8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_f16_acc(f32x16& d, const h8& a, const h8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
+
 // v (fp32) -> hi, lo (fp16, round toward zero; lo absorbs hi's truncation error exactly)
 __device__ __forceinline__ void split4(const f32x4 v, fp16x2& h01, fp16x2& h23, fp16x2& l01, fp16x2& l23) {
     h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
@@ -88,11 +109,15 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     const int L = p.L;
     const int nchunks = (L - 1) * 8;
 
-    const f32x4* l0T = reinterpret_cast<const f32x4*>(smem + LY::l0);
-    const float* woutT = reinterpret_cast<const float*>(smem + LY::wout);
-    const float* zeroT = reinterpret_cast<const float*>(smem + LY::zero);
-    const float* biasT = reinterpret_cast<const float*>(smem + LY::bias);
+    // Per-lane byte bases of the LDS tables.  Every table access below is `base + compile-time
+    // constant` so that it folds into the ds_read offset field: written as index arithmetic on the
+    // lane id, hipcc materialises (and then spills) one address VGPR per unrolled access.
+    const unsigned char* l0B = smem + LY::l0 + half * 64;      // float4 per feature, features 4*half..
+    const unsigned char* woutB = smem + LY::wout + half * 16;  // float per feature
+    const unsigned char* zeroB = smem + LY::zero + half * 16;
+    const unsigned char* biasB = smem + LY::bias + half * 16;
     float* modT = reinterpret_cast<float*>(smem + LY::mods(L)) + wave * (L * 256);
+    const unsigned char* modB = reinterpret_cast<const unsigned char*>(modT) + half * 16;
 
     // ---- once per workgroup: constant tables ------------------------------------------------------
     {
@@ -132,8 +157,6 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
 
     h8 Xh[16], Xl[16], Yh[16], Yl[16];
     f32x16 acc[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;  // the first "pending" epilogue reads acc[1]
     float part = 0.f;
 
     // epilogue of one 32-feature tile, in four parts (g = 0..3: features 8g..8g+7 of the tile, 4 per
@@ -141,78 +164,113 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     // k-step 2t and parts 2,3 k-step 2t+1 of the next layer's B operand.  Also accumulates last_layer's
     // dot product with `wo` (the zero table on all but the final hidden layer).
     fp16x2 eh[4][2], el[4][2];
-    auto epi_part = [&](const f32x16& a, int l, int t, int g, const float* wo) {
-        const float winv = p.winv[l - 1];
-        const int fo = 32 * t + 8 * g + 4 * half;
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(biasT + (l - 1) * 256 + fo);
-        const f32x4 m4 = *reinterpret_cast<const f32x4*>(modT + l * 256 + fo);
+    auto epi_part = [&](const f32x16& a, float winv, float cgl, const unsigned char* bl, const unsigned char* ml,
+                        const unsigned char* wo, int t, int g) {
+        const int fo = (32 * t + 8 * g) * 4;  // compile-time byte offset
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + fo);
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(ml + fo);
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(wo + fo);
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float r = __builtin_fmaf(a[4 * g + e], winv, b4[e]);
-            v[e] = activate<ACT>(r, p.cg) * m4[e];
+            v[e] = activate<ACT>(r, cgl) * m4[e];
             part = __builtin_fmaf(v[e], w4[e], part);
         }
         split4(v, eh[g][0], eh[g][1], el[g][0], el[g][1]);
     };
-    auto epi_store = [&](bool write, h8& dh0, h8& dl0, h8& dh1, h8& dl1) {
-        const h8 nh0 = pack_h8(eh[0][0], eh[0][1], eh[1][0], eh[1][1]);
-        const h8 nl0 = pack_h8(el[0][0], el[0][1], el[1][0], el[1][1]);
-        const h8 nh1 = pack_h8(eh[2][0], eh[2][1], eh[3][0], eh[3][1]);
-        const h8 nl1 = pack_h8(el[2][0], el[2][1], el[3][0], el[3][1]);
-        dh0 = write ? nh0 : dh0;
-        dl0 = write ? nl0 : dl0;
-        dh1 = write ? nh1 : dh1;
-        dl1 = write ? nl1 : dl1;
+    auto epi_store = [&](h8& dh0, h8& dl0, h8& dh1, h8& dl1) {
+        dh0 = to_acc_file(pack_h8(eh[0][0], eh[0][1], eh[1][0], eh[1][1]));
+        dl0 = to_acc_file(pack_h8(el[0][0], el[0][1], el[1][0], el[1][1]));
+        dh1 = to_acc_file(pack_h8(eh[2][0], eh[2][1], eh[3][0], eh[3][1]));
+        dl1 = to_acc_file(pack_h8(el[2][0], el[2][1], el[3][0], el[3][1]));
     };
 
     // one hidden layer: IN -> OUT.  `pend` = the previous hidden layer's last tile still sits in acc[1]
     // and its epilogue (which produces IN[14], IN[15]) is issued inside this layer's first tile.
     // A tile = 4 groups of 4 k-steps (12 MFMAs); each group's scheduling region also holds the LDS
     // reads of the next group's weight fragments and one quarter of the previous tile's epilogue.
-#define MSIREN_F16_LAYER(INh, INl, OUTh, OUTl, LIDX, PEND)                                                    \
-    do {                                                                                                      \
-        const int l_ = (LIDX);                                                                                \
-        const float* wo_ = (l_ == L - 1) ? woutT : zeroT;                                                     \
-        _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                                       \
-            dma_chunk(cg + R - 1);                                                                            \
-            const h8* ring_ = reinterpret_cast<const h8*>(smem + LY::ring + (cg % R) * F16_CHUNK_BYTES) + lane; \
-            f32x16 a_;                                                                                        \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) a_[r] = 0.f;                                       \
-            h8 wf_[2][8];                                                                                     \
-            _Pragma("unroll") for (int i = 0; i < 8; ++i) wf_[0][i] = ring_[i * 64];                          \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
-                __builtin_amdgcn_sched_barrier(0);                                                            \
-                if (q < 3) {                                                                                  \
-                    _Pragma("unroll") for (int i = 0; i < 8; ++i) wf_[(q + 1) & 1][i] = ring_[(8 * (q + 1) + i) * 64]; \
-                }                                                                                             \
-                if (t == 0) {                                                                                 \
-                    /* pending tile of the previous layer feeds k-steps 14, 15 of THIS tile (group 3): */    \
-                    /* all four parts in groups 0-1, stored in group 2 */                                     \
-                    if (q < 2) {                                                                              \
-                        epi_part(acc[1], l_ > 1 ? l_ - 1 : 1, 7, 2 * q, zeroT);                               \
-                        epi_part(acc[1], l_ > 1 ? l_ - 1 : 1, 7, 2 * q + 1, zeroT);                           \
-                    }                                                                                         \
-                    if (q == 2) epi_store((PEND), INh[14], INl[14], INh[15], INl[15]);                        \
-                } else {                                                                                      \
-                    epi_part(acc[(t - 1) & 1], l_, t - 1, q, wo_);                                            \
-                }                                                                                             \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
-                    const int s = 4 * q + j;                                                                  \
-                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf_[q & 1][2 * j + 1], INh[s], a_, 0, 0, 0);  \
-                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf_[q & 1][2 * j], INl[s], a_, 0, 0, 0);      \
-                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf_[q & 1][2 * j], INh[s], a_, 0, 0, 0);      \
-                }                                                                                             \
-            }                                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-            if (t > 0) epi_store(true, OUTh[2 * t - 2], OUTl[2 * t - 2], OUTh[2 * t - 1], OUTl[2 * t - 1]);   \
-            acc[t & 1] = a_;                                                                                  \
-            ++cg;                                                                                             \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 8) : "memory");                                \
-            __builtin_amdgcn_s_barrier();                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-        }                                                                                                     \
+    // The tile / group / k-step structure is expanded by the preprocessor, not by `#pragma unroll`:
+    // with asm statements in the body hipcc only partially unrolls, the activation arrays then get
+    // runtime indices and are demoted to scratch memory.
+#define MSIREN_F16_KSTEP(INh, INl, T, Q, J)                                                   \
+    do {                                                                                      \
+        if (2 * (Q) + (J) == 0) mfma_f16_first(acc[(T) & 1], wf_[(Q) & 1][2 * (J) + 1], INh[2 * (Q) + (J)]); \
+        else mfma_f16_acc(acc[(T) & 1], wf_[(Q) & 1][2 * (J) + 1], INh[2 * (Q) + (J)]);       \
+        mfma_f16_acc(acc[(T) & 1], wf_[(Q) & 1][2 * (J)], INl[2 * (Q) + (J)]);                \
+        mfma_f16_acc(acc[(T) & 1], wf_[(Q) & 1][2 * (J)], INh[2 * (Q) + (J)]);                \
+    } while (0)
+
+    // group Q of tile T: 2 k-steps (6 MFMAs, 192 cycles) + the LDS reads of group Q+1 + a slice of the
+    // previous tile's epilogue, all in one scheduling region
+#define MSIREN_F16_GROUP(INh, INl, T, Q)                                                      \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if ((Q) < 7) {                                                                        \
+            wf_[((Q) + 1) & 1][0] = ring_[(4 * ((Q) + 1) + 0) * 64];                          \
+            wf_[((Q) + 1) & 1][1] = ring_[(4 * ((Q) + 1) + 1) * 64];                          \
+            wf_[((Q) + 1) & 1][2] = ring_[(4 * ((Q) + 1) + 2) * 64];                          \
+            wf_[((Q) + 1) & 1][3] = ring_[(4 * ((Q) + 1) + 3) * 64];                          \
+        }                                                                                     \
+        if ((T) == 0) {                                                                       \
+            /* pending tile of the previous layer feeds k-steps 14, 15 of THIS tile (group 7): */ \
+            /* its four parts go into groups 0-3, the store into group 4 */                   \
+            if ((Q) < 4) epi_part(acc[1], wip_, cgp_, blp_, mlp_, zeroB, 7, (Q) & 3);         \
+            if ((Q) == 4) epi_store(INh[14], INl[14], INh[15], INl[15]);                      \
+        } else {                                                                              \
+            if (((Q) & 1) == 0) epi_part(acc[((T) + 1) & 1], wi_, p.cg, bl_, ml_, wo_, ((T) + 7) & 7, (Q) >> 1); \
+        }                                                                                     \
+        MSIREN_F16_KSTEP(INh, INl, T, Q, 0);                                                  \
+        MSIREN_F16_KSTEP(INh, INl, T, Q, 1);                                                  \
+    } while (0)
+
+#define MSIREN_F16_TILE(INh, INl, OUTh, OUTl, T)                                              \
+    do {                                                                                      \
+        dma_chunk(cg + R - 1);                                                                \
+        const h8* ring_ = reinterpret_cast<const h8*>(smem + LY::ring + (cg % R) * F16_CHUNK_BYTES) + lane; \
+        h8 wf_[2][4];                                                                         \
+        wf_[0][0] = ring_[0 * 64];                                                            \
+        wf_[0][1] = ring_[1 * 64];                                                            \
+        wf_[0][2] = ring_[2 * 64];                                                            \
+        wf_[0][3] = ring_[3 * 64];                                                            \
+        MSIREN_F16_GROUP(INh, INl, T, 0);                                                     \
+        MSIREN_F16_GROUP(INh, INl, T, 1);                                                     \
+        MSIREN_F16_GROUP(INh, INl, T, 2);                                                     \
+        MSIREN_F16_GROUP(INh, INl, T, 3);                                                     \
+        MSIREN_F16_GROUP(INh, INl, T, 4);                                                     \
+        MSIREN_F16_GROUP(INh, INl, T, 5);                                                     \
+        MSIREN_F16_GROUP(INh, INl, T, 6);                                                     \
+        MSIREN_F16_GROUP(INh, INl, T, 7);                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if ((T) > 0) epi_store(OUTh[(2 * (T) + 14) & 15], OUTl[(2 * (T) + 14) & 15], OUTh[(2 * (T) + 15) & 15], OUTl[(2 * (T) + 15) & 15]); \
+        ++cg;                                                                                 \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 8) : "memory");                    \
+        __builtin_amdgcn_s_barrier();                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+
+    // one hidden layer: IN -> OUT.  The previous layer's last tile still sits in acc[1]; its epilogue
+    // (which produces IN[14], IN[15]) is issued inside this layer's first tile.  For l_ == 1 the
+    // "previous layer" is layer 0, whose arguments were left in acc[1] in revolutions: inverse scale 1,
+    // no bias, layer-0 modulation and Morlet constant.
+#define MSIREN_F16_LAYER(INh, INl, OUTh, OUTl, LIDX)                                          \
+    do {                                                                                      \
+        const int l_ = (LIDX);                                                                \
+        const unsigned char* wo_ = (l_ == L - 1) ? woutB : zeroB;                             \
+        const unsigned char* bl_ = biasB + (l_ - 1) * 1024;                                   \
+        const unsigned char* ml_ = modB + l_ * 1024;                                          \
+        const unsigned char* blp_ = l_ > 1 ? biasB + (l_ - 2) * 1024 : zeroB;                 \
+        const unsigned char* mlp_ = modB + (l_ - 1) * 1024;                                   \
+        const float wi_ = p.winv[l_ - 1], wip_ = l_ > 1 ? p.winv[l_ - 2] : 1.0f;              \
+        const float cgp_ = l_ > 1 ? p.cg : p.cg0;                                             \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 0);                                             \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 1);                                             \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 2);                                             \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 3);                                             \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 4);                                             \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 5);                                             \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 6);                                             \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 7);                                             \
     } while (0)
 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 8) : "memory");
@@ -236,40 +294,57 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         const float2 xy = reinterpret_cast<const float2*>(p.grid)[pc];
 
         // ---- layer 0 (K = 2) directly in B-operand order: element j of k-step s is feature
-        //      32*(s>>1) + 16*(s&1) + 8*(j>>2) + 4*half + (j&3)
+        //      32*(s>>1) + 16*(s&1) + 8*(j>>2) + 4*half + (j&3).  K-steps 0..13 are finished here; the
+        //      last 32 features (k-steps 14, 15 = "tile 7") are left as sine ARGUMENTS in acc[1], where
+        //      the first hidden layer's pending-epilogue slot turns them into X[14], X[15].
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < 14; ++s) {
             fp16x2 hh[2][2], ll[2][2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int f0 = 32 * (s >> 1) + 16 * (s & 1) + 8 * q + 4 * half;
-                const f32x4 m4 = *reinterpret_cast<const f32x4*>(modT + f0);
+                const int f0 = 32 * (s >> 1) + 16 * (s & 1) + 8 * q;  // + 4*half, carried by the bases
+                const f32x4 m4 = *reinterpret_cast<const f32x4*>(modB + f0 * 4);
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const f32x4 w = l0T[f0 + e];
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(l0B + (f0 + e) * 16);
                     const float r = __builtin_fmaf(xy.y, w[1], __builtin_fmaf(xy.x, w[0], w[2]));
                     v[e] = activate<ACT>(r, p.cg0) * m4[e];
                 }
                 split4(v, hh[q][0], hh[q][1], ll[q][0], ll[q][1]);
             }
-            Xh[s] = pack_h8(hh[0][0], hh[0][1], hh[1][0], hh[1][1]);
-            Xl[s] = pack_h8(ll[0][0], ll[0][1], ll[1][0], ll[1][1]);
+            Xh[s] = to_acc_file(pack_h8(hh[0][0], hh[0][1], hh[1][0], hh[1][1]));
+            Xl[s] = to_acc_file(pack_h8(ll[0][0], ll[0][1], ll[1][0], ll[1][1]));
+        }
+        {
+            f32x16 r7;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(l0B + (224 + 8 * g + e) * 16);
+                    r7[4 * g + e] = __builtin_fmaf(xy.y, w[1], __builtin_fmaf(xy.x, w[0], w[2]));
+                }
+            acc[1] = r7;
         }
 
         part = 0.f;
         for (int l = 1; l < L; l += 2) {
-            MSIREN_F16_LAYER(Xh, Xl, Yh, Yl, l, l > 1);
-            if (l + 1 < L) MSIREN_F16_LAYER(Yh, Yl, Xh, Xl, l + 1, true);
+            MSIREN_F16_LAYER(Xh, Xl, Yh, Yl, l);
+            if (l + 1 < L) MSIREN_F16_LAYER(Yh, Yl, Xh, Xl, l + 1);
         }
         // the final hidden layer's last tile is still pending: only its contribution to `part` matters
 #pragma unroll
-        for (int g = 0; g < 4; ++g) epi_part(acc[1], L - 1, 7, g, woutT);
+        for (int g = 0; g < 4; ++g)
+            epi_part(acc[1], p.winv[L - 2], p.cg, biasB + (L - 2) * 1024, modB + (L - 1) * 1024, woutB, 7, g);
         part += __shfl_xor(part, 32);
         if (pvalid && half == 0) p.out[(size_t)b * p.P + pc] = sin_rev(part + p.bout);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may be in flight when the LDS is released
 #undef MSIREN_F16_LAYER
+#undef MSIREN_F16_TILE
+#undef MSIREN_F16_GROUP
+#undef MSIREN_F16_KSTEP
 }
 
 }  // namespace msiren
