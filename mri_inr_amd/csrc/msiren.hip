@@ -464,6 +464,8 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     const int64_t units = B * p.units_per_patch;
     if (units > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     p.total_units = (int)units;
+    p.dbg_flags = 0;
+    if (const char* e = std::getenv("MSIREN_F16_FLAGS")) p.dbg_flags = std::atoi(e);
     const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
     if (msiren::F16Lds<4>::total(h->L) <= 160 * 1024) return launch_trunk_f16x3_r<4>(h, p, grid);
     return launch_trunk_f16x3_r<3>(h, p, grid);

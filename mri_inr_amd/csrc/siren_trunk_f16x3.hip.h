@@ -44,6 +44,7 @@ struct TrunkF16Params {
     float winv[16];           // per hidden layer: exact inverse of the power-of-two weight scale
     float bout, cg0, cg;
     int B, P, L, units_per_patch, total_units;
+    int dbg_flags;            // experiment knobs (MSIREN_F16_FLAGS): 1 = skip the weight DMA (timing only, wrong results)
 };
 
 constexpr int F16_CHUNK_BYTES = 32768;
@@ -83,10 +84,13 @@ __device__ __forceinline__ h8 to_acc_file(h8 v) {
 // every B fragment is written at least one scheduling group (>100 cycles) before its first use, and
 // an accumulator is read by VALU only in the NEXT tile, behind an s_barrier.
 __device__ __forceinline__ void mfma_f16_first(f32x16& d, const h8& a, const h8& b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, z, 0, 0, 0);
 }
 __device__ __forceinline__ void mfma_f16_acc(f32x16& d, const h8& a, const h8& b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, d, 0, 0, 0);
 }
 
 // v (fp32) -> hi, lo (fp16, round toward zero; lo absorbs hi's truncation error exactly)
@@ -137,23 +141,36 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     const int upp = 4 * G;  // units per pass over the whole grid
     const int npass = (p.total_units - 4 * (int)blockIdx.x + upp - 1) / upp;  // passes of THIS workgroup (>= 0)
     const int total_chunks = npass * nchunks;
-    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wp) + wave * 8192 + lane * 16;
-    auto dma_chunk = [&](int seq) {  // every wave moves its 8 KB slice of chunk `seq`
-        if (seq < total_chunks) {
-            const int id = seq % nchunks;
-            const int buf = seq % R;
-            const unsigned char* src = wsrc + (size_t)id * F16_CHUNK_BYTES;
-            unsigned char* dst = smem + LY::ring + buf * F16_CHUNK_BYTES + wave * 8192;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    // each wave moves its 8 KB slice of a chunk: 8 x 1 KB global_load_lds_dwordx4, one base address
+    // pair (biased by +4 KB so that the eight 1 KB steps fit the 13-bit signed immediate, which the
+    // instruction applies to the global AND the LDS address)
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wp) + wave * 8192 + lane * 16 + 4096;
+    int dma_id = 0, dma_buf = 0, rd_buf = 0;
+    auto dma_next = [&]() {
+        {   // unconditional: past the last chunk the ring is refilled with (unused) wrapped-around data;
+            // the kernel drains vmcnt before it exits
+
+            const unsigned char* src = wsrc + (size_t)dma_id * F16_CHUNK_BYTES;
+            unsigned char* dst = smem + LY::ring + dma_buf * F16_CHUNK_BYTES + wave * 8192 + 4096;
+#define MSIREN_DMA(I)                                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,                  \
+                                     (__attribute__((address_space(3))) void*)dst, 16, (I) * 1024 - 4096, 0)
+            MSIREN_DMA(0);
+            MSIREN_DMA(1);
+            MSIREN_DMA(2);
+            MSIREN_DMA(3);
+            MSIREN_DMA(4);
+            MSIREN_DMA(5);
+            MSIREN_DMA(6);
+            MSIREN_DMA(7);
+#undef MSIREN_DMA
         }
+        dma_id = dma_id + 1 == nchunks ? 0 : dma_id + 1;
+        dma_buf = dma_buf + 1 == R ? 0 : dma_buf + 1;
     };
     if (npass <= 0) return;
 #pragma unroll
-    for (int s = 0; s < R - 1; ++s) dma_chunk(s);
-    int cg = 0;
+    for (int s = 0; s < R - 1; ++s) dma_next();
 
     h8 Xh[16], Xl[16], Yh[16], Yl[16];
     f32x16 acc[2];
@@ -164,32 +181,42 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     // k-step 2t and parts 2,3 k-step 2t+1 of the next layer's B operand.  Also accumulates last_layer's
     // dot product with `wo` (the zero table on all but the final hidden layer).
     fp16x2 eh[4][2], el[4][2];
-    auto epi_part = [&](const f32x16& a, float winv, float cgl, const unsigned char* bl, const unsigned char* ml,
-                        const unsigned char* wo, int t, int g) {
+    // bias / modulation / last_layer weight of the epilogue part in flight and of the next one
+    // (two register sets, loaded one scheduling group ahead of their use)
+    f32x4 tb_b[2], tb_m[2], tb_w[2];
+    auto tbl_load = [&](int set, const unsigned char* bl, const unsigned char* ml, const unsigned char* wo, int t, int g) {
         const int fo = (32 * t + 8 * g) * 4;  // compile-time byte offset
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bl + fo);
-        const f32x4 m4 = *reinterpret_cast<const f32x4*>(ml + fo);
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wo + fo);
-        f32x4 v;
+        tb_b[set] = *reinterpret_cast<const f32x4*>(bl + fo);
+        tb_m[set] = *reinterpret_cast<const f32x4*>(ml + fo);
+        tb_w[set] = *reinterpret_cast<const f32x4*>(wo + fo);
+    };
+    // half `hh` (elements 2hh, 2hh+1) of part g of an accumulator tile: acc -> (revolutions) -> activation
+    // -> modulation -> fp16 hi/lo pair; also accumulates last_layer's dot product (the weight table is
+    // all zeros except on the final hidden layer)
+    auto epi_half = [&](const f32x16& a, float winv, float cgl, int set, int g, int hh) {
+        // The two accumulator elements pass through an opaque asm: instruction selection orders pure
+        // VALU code only by data dependence, so without an anchor the whole tile's epilogue is emitted
+        // in one block ahead of the MFMAs and the sched_barrier-delimited groups are empty of VALU.
+        float a0 = a[4 * g + 2 * hh], a1 = a[4 * g + 2 * hh + 1];
+        asm volatile("; epilogue slice anchored to its MFMA group" : "+v"(a0), "+v"(a1));
+        const float ain[2] = {a0, a1};
+        float v[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float r = __builtin_fmaf(a[4 * g + e], winv, b4[e]);
-            v[e] = activate<ACT>(r, cgl) * m4[e];
-            part = __builtin_fmaf(v[e], w4[e], part);
+        for (int e = 0; e < 2; ++e) {
+            const float r = __builtin_fmaf(ain[e], winv, tb_b[set][2 * hh + e]);
+            v[e] = activate<ACT>(r, cgl) * tb_m[set][2 * hh + e];
+            part = __builtin_fmaf(v[e], tb_w[set][2 * hh + e], part);
         }
-        split4(v, eh[g][0], eh[g][1], el[g][0], el[g][1]);
+        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+        eh[g][hh] = h;
+        el[g][hh] = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h[0], v[1] - (float)h[1]);
     };
-    auto epi_store = [&](h8& dh0, h8& dl0, h8& dh1, h8& dl1) {
-        dh0 = to_acc_file(pack_h8(eh[0][0], eh[0][1], eh[1][0], eh[1][1]));
-        dl0 = to_acc_file(pack_h8(el[0][0], el[0][1], el[1][0], el[1][1]));
-        dh1 = to_acc_file(pack_h8(eh[2][0], eh[2][1], eh[3][0], eh[3][1]));
-        dl1 = to_acc_file(pack_h8(el[2][0], el[2][1], el[3][0], el[3][1]));
+    auto epi_store2 = [&](int ks, h8& dh, h8& dl) {  // k-step ks (0/1) of the tile = parts 2ks, 2ks+1
+        dh = to_acc_file(pack_h8(eh[2 * ks][0], eh[2 * ks][1], eh[2 * ks + 1][0], eh[2 * ks + 1][1]));
+        dl = to_acc_file(pack_h8(el[2 * ks][0], el[2 * ks][1], el[2 * ks + 1][0], el[2 * ks + 1][1]));
     };
+    h8 wf_[2][4];  // weight fragments of the k-step group in flight / the next one
 
-    // one hidden layer: IN -> OUT.  `pend` = the previous hidden layer's last tile still sits in acc[1]
-    // and its epilogue (which produces IN[14], IN[15]) is issued inside this layer's first tile.
-    // A tile = 4 groups of 4 k-steps (12 MFMAs); each group's scheduling region also holds the LDS
-    // reads of the next group's weight fragments and one quarter of the previous tile's epilogue.
     // The tile / group / k-step structure is expanded by the preprocessor, not by `#pragma unroll`:
     // with asm statements in the body hipcc only partially unrolls, the activation arrays then get
     // runtime indices and are demoted to scratch memory.
@@ -201,52 +228,82 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         mfma_f16_acc(acc[(T) & 1], wf_[(Q) & 1][2 * (J)], INh[2 * (Q) + (J)]);                \
     } while (0)
 
-    // group Q of tile T: 2 k-steps (6 MFMAs, 192 cycles) + the LDS reads of group Q+1 + a slice of the
-    // previous tile's epilogue, all in one scheduling region
-#define MSIREN_F16_GROUP(INh, INl, T, Q)                                                      \
+    // Group Q of tile T = one scheduling region: 2 k-steps (6 MFMAs, 192 cycles), the LDS reads of the
+    // NEXT group's weight fragments (for Q == 7: the next tile's first group, from the next ring
+    // buffer, which the mid-tile barrier has already published), one slice of the previous tile's
+    // epilogue, and the table reads of the epilogue part after that.
+    // Epilogue schedule.  T > 0: tile T-1, half (Q&1) of part Q>>1 per group; T == 0: the previous layer's
+    // tile 7 ("pending"), whose result feeds k-steps 14, 15 of THIS tile, so: parts 0..3 in groups 0..3,
+    // stores in groups 4 and 5.
+#define MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, Q)                                          \
     do {                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        if ((Q) < 7) {                                                                        \
-            wf_[((Q) + 1) & 1][0] = ring_[(4 * ((Q) + 1) + 0) * 64];                          \
-            wf_[((Q) + 1) & 1][1] = ring_[(4 * ((Q) + 1) + 1) * 64];                          \
-            wf_[((Q) + 1) & 1][2] = ring_[(4 * ((Q) + 1) + 2) * 64];                          \
-            wf_[((Q) + 1) & 1][3] = ring_[(4 * ((Q) + 1) + 3) * 64];                          \
+        {                                                                                     \
+            const h8* src_ = (Q) < 7 ? ring_ + (4 * (((Q) + 1) & 7)) * 64 : ringn_;           \
+            wf_[((Q) + 1) & 1][0] = src_[0 * 64];                                             \
+            wf_[((Q) + 1) & 1][1] = src_[1 * 64];                                             \
+            wf_[((Q) + 1) & 1][2] = src_[2 * 64];                                             \
+            wf_[((Q) + 1) & 1][3] = src_[3 * 64];                                             \
         }                                                                                     \
         if ((T) == 0) {                                                                       \
-            /* pending tile of the previous layer feeds k-steps 14, 15 of THIS tile (group 7): */ \
-            /* its four parts go into groups 0-3, the store into group 4 */                   \
-            if ((Q) < 4) epi_part(acc[1], wip_, cgp_, blp_, mlp_, zeroB, 7, (Q) & 3);         \
-            if ((Q) == 4) epi_store(INh[14], INl[14], INh[15], INl[15]);                      \
+            if ((Q) < 3) tbl_load(((Q) + 1) & 1, blp_, mlp_, zeroB, 7, ((Q) + 1) & 3);        \
+            if ((Q) < 4) {                                                                    \
+                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 0);                            \
+                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 1);                            \
+            }                                                                                 \
+            if ((Q) == 4) epi_store2(0, INh[14], INl[14]);                                    \
+            if ((Q) == 5) epi_store2(1, INh[15], INl[15]);                                    \
         } else {                                                                              \
-            if (((Q) & 1) == 0) epi_part(acc[((T) + 1) & 1], wi_, p.cg, bl_, ml_, wo_, ((T) + 7) & 7, (Q) >> 1); \
+            if (((Q) & 1) == 1 && (Q) < 7) tbl_load((((Q) >> 1) + 1) & 1, bl_, ml_, wo_, ((T) + 7) & 7, (((Q) >> 1) + 1) & 3); \
+            epi_half(acc[((T) + 1) & 1], wi_, p.cg, ((Q) >> 1) & 1, (Q) >> 1, (Q) & 1);       \
+            if ((Q) == 5) epi_store2(0, OUTh[(2 * (T) + 14) & 15], OUTl[(2 * (T) + 14) & 15]); \
         }                                                                                     \
+        if ((Q) == 7) tbl_load(0, bl_, ml_, wo_, (T), 0); /* part 0 of THIS tile's epilogue (runs next tile) */ \
         MSIREN_F16_KSTEP(INh, INl, T, Q, 0);                                                  \
         MSIREN_F16_KSTEP(INh, INl, T, Q, 1);                                                  \
+        /* requested issue order inside the region: the weight-fragment reads first, VALU spread */ \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                    \
     } while (0)
 
+    // One tile = one 32 KB weight chunk.  The ring is synchronised in the MIDDLE of the tile: by then
+    // every wave has finished the previous tile (so its buffer may be refilled: DMA of chunk c+R-1) and,
+    // after the counted vmcnt + barrier, chunk c+1 is visible to all -- early enough for group 7 to
+    // prefetch the next tile's first weight fragments, so no LDS latency is exposed at tile boundaries.
 #define MSIREN_F16_TILE(INh, INl, OUTh, OUTl, T)                                              \
     do {                                                                                      \
-        dma_chunk(cg + R - 1);                                                                \
-        const h8* ring_ = reinterpret_cast<const h8*>(smem + LY::ring + (cg % R) * F16_CHUNK_BYTES) + lane; \
-        h8 wf_[2][4];                                                                         \
-        wf_[0][0] = ring_[0 * 64];                                                            \
-        wf_[0][1] = ring_[1 * 64];                                                            \
-        wf_[0][2] = ring_[2 * 64];                                                            \
-        wf_[0][3] = ring_[3 * 64];                                                            \
-        MSIREN_F16_GROUP(INh, INl, T, 0);                                                     \
-        MSIREN_F16_GROUP(INh, INl, T, 1);                                                     \
-        MSIREN_F16_GROUP(INh, INl, T, 2);                                                     \
-        MSIREN_F16_GROUP(INh, INl, T, 3);                                                     \
-        MSIREN_F16_GROUP(INh, INl, T, 4);                                                     \
-        MSIREN_F16_GROUP(INh, INl, T, 5);                                                     \
-        MSIREN_F16_GROUP(INh, INl, T, 6);                                                     \
-        MSIREN_F16_GROUP(INh, INl, T, 7);                                                     \
+        const h8* ring_ = reinterpret_cast<const h8*>(smem + LY::ring + rd_buf * F16_CHUNK_BYTES) + lane; \
+        rd_buf = rd_buf + 1 == R ? 0 : rd_buf + 1;                                            \
+        const h8* ringn_ = reinterpret_cast<const h8*>(smem + LY::ring + rd_buf * F16_CHUNK_BYTES) + lane; \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 0);                                         \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 1);                                         \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 2);                                         \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 3);                                         \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        if ((T) > 0) epi_store(OUTh[(2 * (T) + 14) & 15], OUTl[(2 * (T) + 14) & 15], OUTh[(2 * (T) + 15) & 15], OUTl[(2 * (T) + 15) & 15]); \
-        ++cg;                                                                                 \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 8) : "memory");                    \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 8) : "memory");                    \
         __builtin_amdgcn_s_barrier();                                                         \
+        dma_next();                                                                           \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 4);                                         \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 5);                                         \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 6);                                         \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 7);                                         \
         __builtin_amdgcn_sched_barrier(0);                                                    \
+        if ((T) > 0) epi_store2(1, OUTh[(2 * (T) + 15) & 15], OUTl[(2 * (T) + 15) & 15]);     \
     } while (0)
 
     // one hidden layer: IN -> OUT.  The previous layer's last tile still sits in acc[1]; its epilogue
@@ -275,6 +332,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 8) : "memory");
     __syncthreads();  // tables + first chunk visible
+    {   // first weight fragments of the very first tile
+        const h8* r0 = reinterpret_cast<const h8*>(smem + LY::ring) + lane;
+        wf_[0][0] = r0[0 * 64];
+        wf_[0][1] = r0[1 * 64];
+        wf_[0][2] = r0[2 * 64];
+        wf_[0][3] = r0[3 * 64];
+    }
 
     for (int pass = 0; pass < npass; ++pass) {
         int unit = (pass * G + (int)blockIdx.x) * 4 + wave;
@@ -327,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
                 }
             acc[1] = r7;
         }
+        tbl_load(0, zeroB, modB, zeroB, 7, 0);  // part 0 of the layer-0 "pending" tile
 
         part = 0.f;
         for (int l = 1; l < L; l += 2) {
@@ -335,8 +400,11 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         }
         // the final hidden layer's last tile is still pending: only its contribution to `part` matters
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            epi_part(acc[1], p.winv[L - 2], p.cg, biasB + (L - 2) * 1024, modB + (L - 1) * 1024, woutB, 7, g);
+        for (int g = 0; g < 4; ++g) {
+            if (g > 0) tbl_load(g & 1, biasB + (L - 2) * 1024, modB + (L - 1) * 1024, woutB, 7, g);
+            epi_half(acc[1], p.winv[L - 2], p.cg, g & 1, g, 0);
+            epi_half(acc[1], p.winv[L - 2], p.cg, g & 1, g, 1);
+        }
         part += __shfl_xor(part, 32);
         if (pvalid && half == 0) p.out[(size_t)b * p.P + pc] = sin_rev(part + p.bout);
     }
