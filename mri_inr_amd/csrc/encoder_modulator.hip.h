@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void modulator_layer_mfma_kernel(ModulatorMfma
     const float* hrow = p.hprev ? p.hprev + (size_t)row * p.H + 4 * kq : nullptr;
     const float* zrow = p.z + (size_t)row * p.Z + 4 * kq;
     mod_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 8
     for (int blk = b_lo; blk < b_hi; ++blk) {
         const int k0 = blk * 16;
         const mod_f32x4 a = *reinterpret_cast<const mod_f32x4*>(k0 < p.Kh ? hrow + k0 : zrow + (k0 - p.Kh));
