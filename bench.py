@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3"],
                     help="trunk arithmetic: f16x3 = split-fp16, 3 f16 MFMAs per product, fp32-equivalent accuracy "
                          "(default); fp32 = v_mfma_f32_32x32x2_f32")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
+                    help="2 = consecutive steps alternate between two HIP streams (independent slices overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--check", action="store_true", help="also verify one batch against the oracle")
@@ -134,12 +136,18 @@ def main():
     B = n_sl * 400
     d_img = model.device_array(imgs.shape).copy_from(imgs)
     d_tiles = model.device_array((B, 32, 32))
-    d_out = model.device_array((B, 24, 24))
+    d_outs = [model.device_array((B, 24, 24)) for _ in range(2)]
+    d_out = d_outs[0]
+    _lib.check(lib.msiren_set_streams(h, args.streams))
     _lib.check(lib.msiren_image_to_patches_dev(h, d_img.ptr, n_sl, 320, 320, d_tiles.ptr))
     model.sync()
 
+    nstep = [0]
+
     def step():
-        _lib.check(lib.msiren_forward_tiles_dev(h, d_tiles.ptr, B, d_out.ptr))
+        # consecutive steps are independent slices: alternate the output buffer with the stream
+        _lib.check(lib.msiren_forward_tiles_dev(h, d_tiles.ptr, B, d_outs[nstep[0] & 1].ptr))
+        nstep[0] += 1
 
     def fence():
         model.sync()
@@ -197,7 +205,7 @@ def main():
                         f"ModulatedSiren.forward (encoder+modulator+fused trunk, {args.activation}) -> {B}x24x24; "
                         "tiles and outputs resident in HBM",
             "slices_per_gpu_per_step": n_sl, "patches_per_step_per_gpu": B, "coords_per_patch": 576,
-            "dim_hidden": 256, "num_layers": 5, "activation": args.activation, "precision": args.precision,
+            "dim_hidden": 256, "num_layers": 5, "activation": args.activation, "precision": args.precision, "streams": args.streams,
             "parallelism": f"patch-shard x{world}",
         },
         "roofline": {

@@ -147,7 +147,15 @@ MSIREN_API int msiren_image_to_patches_dev(msiren_handle h, const float* images_
 MSIREN_API int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev /* (n*nV*nH, S, S) */, int64_t n_slices,
                              int32_t n_vertical, int32_t n_horizontal, float* recon_dev);
 
-/* Blocks until everything enqueued on the handle's stream has finished (the reference's implicit
+/* Pipelining of asynchronous calls.  n = 1 (default): every *_dev call is enqueued on one stream and
+ * executes in call order.  n = 2: consecutive *_dev FORWARD calls (forward_mods/latent/tiles_dev,
+ * reconstruct_slices_dev) alternate between two streams with private scratch, so independent calls
+ * overlap on the device (the under-occupied tail of one call's trunk kernel is filled by the next
+ * call's kernels).  The caller then must not hand the same output buffer to two consecutive calls,
+ * nor feed one call's output to the next, without an msiren_sync() in between. */
+MSIREN_API int msiren_set_streams(msiren_handle h, int32_t n);
+
+/* Blocks until everything enqueued on the handle's streams has finished (the reference's implicit
  * synchronisation at .cpu(), error.py:256-258). */
 MSIREN_API int msiren_sync(msiren_handle h);
 

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "msiren_image_to_patches_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "msiren_weighted_fold_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "msiren_sync": (C.c_int, [_vp]),
+    "msiren_set_streams": (C.c_int, [_vp, _i32]),
     "msiren_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "msiren_dev_free": (C.c_int, [_vp, _vp]),
     "msiren_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

@@ -53,7 +53,14 @@ struct DevBuf {
 struct msiren_ctx {
     msiren_config cfg{};
     int H = 0, HP = 0, L = 0, Z = 0, S = 0, P = 0, O = 0, I = 0;
-    hipStream_t stream = nullptr;
+    // Up to two streams with private scratch: with msiren_set_streams(h, 2) consecutive *_dev forward
+    // calls alternate between them, so the under-occupied tail of one call's persistent trunk kernel
+    // overlaps the encoder / modulator / trunk start of the next call.
+    struct StreamCtx {
+        hipStream_t s = nullptr;
+        DevBuf mods, modpad, latent, patches, keep, rec;
+    } sc[2];
+    int cur = 0, nstreams = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, std::vector<float>> tensors;  // state_dict, host copies
     std::map<std::string, size_t> expected;             // key -> element count
@@ -74,7 +81,7 @@ struct msiren_ctx {
     msiren::EncoderParams enc{};
     float* d_foldw = nullptr;  // (S,S) overlap-add weights
     // workspaces
-    DevBuf ws_mods, ws_modpad, ws_out, ws_latent, ws_tiles, ws_in, ws_patches, ws_keep, ws_rec, ws_img;
+    DevBuf ws_out, ws_tiles, ws_in, ws_img;  // staging of the host-pointer entry points
     // profiling
     bool profile = false;
     int64_t prof_launches = 0;
@@ -396,7 +403,7 @@ int launch_trunk_hp(msiren_ctx* h, const msiren::TrunkParams& p, int grid) {
         auto k = msiren::siren_trunk_f32_kernel<HP, A, R>;                                         \
         if (lds > 64 * 1024)                                                                       \
             HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->stream, p);                           \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);                           \
     } while (0)
     if (act == MSIREN_ACT_MORLET) {
         if (res) MSIREN_LAUNCH(1, 1); else MSIREN_LAUNCH(1, 0);
@@ -437,9 +444,9 @@ int launch_trunk_f16x3_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int gri
     const void* kp = h->cfg.activation == MSIREN_ACT_MORLET ? (const void*)k1 : (const void*)k0;
     HIPCHK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if (h->cfg.activation == MSIREN_ACT_MORLET)
-        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, h->stream, p);
+        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
     else
-        hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, h->stream, p);
+        hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -490,11 +497,11 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
             e0 = h->prof_events[h->prof_used].first;
             e1 = h->prof_events[h->prof_used].second;
             h->prof_used++;
-            HIPCHK(hipEventRecord(e0, h->stream));
+            HIPCHK(hipEventRecord(e0, h->sc[h->cur].s));
         }
         int rc = launch_trunk_f16x3(h, mods_dev, B, out_dev);
         if (rc) return rc;
-        if (h->profile) HIPCHK(hipEventRecord(e1, h->stream));
+        if (h->profile) HIPCHK(hipEventRecord(e1, h->sc[h->cur].s));
         return 0;
     }
     const int chunks = (h->P + 63) / 64;
@@ -502,13 +509,13 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
     const float* mods = mods_dev;
     int stride = h->H;
     if (h->HP != h->H) {  // zero-pad the feature axis once so the kernel can use float4 loads
-        int rc = ensure(h, h->ws_modpad, (size_t)h->L * B * h->HP * sizeof(float));
+        int rc = ensure(h, h->sc[h->cur].modpad, (size_t)h->L * B * h->HP * sizeof(float));
         if (rc) return rc;
         const int64_t n = (int64_t)h->L * B * h->HP;
-        hipLaunchKernelGGL(msiren::pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream,
-                           mods_dev, (float*)h->ws_modpad.p, (int64_t)h->L * B, h->H, h->HP);
+        hipLaunchKernelGGL(msiren::pad_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->sc[h->cur].s,
+                           mods_dev, (float*)h->sc[h->cur].modpad.p, (int64_t)h->L * B, h->H, h->HP);
         HIPCHK(hipGetLastError());
-        mods = (const float*)h->ws_modpad.p;
+        mods = (const float*)h->sc[h->cur].modpad.p;
         stride = h->HP;
     }
     msiren::TrunkParams p = make_trunk_params(h, mods, stride, B, out_dev);
@@ -525,7 +532,7 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
         e0 = h->prof_events[h->prof_used].first;
         e1 = h->prof_events[h->prof_used].second;
         h->prof_used++;
-        HIPCHK(hipEventRecord(e0, h->stream));
+        HIPCHK(hipEventRecord(e0, h->sc[h->cur].s));
     }
     int rc;
     switch (h->HP) {
@@ -536,7 +543,7 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
         default: return fail(MSIREN_E_INVALID, "dim_hidden=%d (padded %d) is not supported by the fp32 trunk (max 512)", h->H, h->HP);
     }
     if (rc) return rc;
-    if (h->profile) HIPCHK(hipEventRecord(e1, h->stream));
+    if (h->profile) HIPCHK(hipEventRecord(e1, h->sc[h->cur].s));
     return 0;
 }
 
@@ -558,7 +565,7 @@ int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_d
         mp.Z = h->Z;
         mp.Kh = Kh;
         dim3 grid((unsigned)((B + 15) / 16), (unsigned)(h->H / 16));
-        hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, grid, dim3(256), 0, h->stream, mp);
+        hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, grid, dim3(256), 0, h->sc[h->cur].s, mp);
         HIPCHK(hipGetLastError());
         off += (size_t)(Kh + h->Z) * h->H;
     }
@@ -578,7 +585,7 @@ int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_d
         mp.Kh = Kh;
         dim3 grid((unsigned)((B + msiren::MOD_ROWS - 1) / msiren::MOD_ROWS), (unsigned)((h->H + 63) / 64));
         const size_t lds = (size_t)msiren::MOD_ROWS * (Kh + h->Z) * sizeof(float);
-        hipLaunchKernelGGL(msiren::modulator_layer_kernel, grid, dim3(256), lds, h->stream, mp);
+        hipLaunchKernelGGL(msiren::modulator_layer_kernel, grid, dim3(256), lds, h->sc[h->cur].s, mp);
         HIPCHK(hipGetLastError());
         off += (size_t)(Kh + h->Z) * h->H;
     }
@@ -588,7 +595,7 @@ int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_d
 int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_dev) {
     if (B == 0) return 0;
     if (!h->have_encoder) return fail(MSIREN_E_STATE, "encoder.* weights were not loaded");
-    hipLaunchKernelGGL(msiren::encoder_kernel, dim3((unsigned)B), dim3(256), 0, h->stream, h->enc, tiles_dev, z_dev);
+    hipLaunchKernelGGL(msiren::encoder_kernel, dim3((unsigned)B), dim3(256), 0, h->sc[h->cur].s, h->enc, tiles_dev, z_dev);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -596,9 +603,9 @@ int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_de
 int forward_latent_dev(msiren_ctx* h, const float* z_dev, int64_t B, float* out_dev, float* mods_out_dev) {
     float* mods = mods_out_dev;
     if (!mods) {
-        int rc = ensure(h, h->ws_mods, (size_t)h->L * B * h->H * sizeof(float));
+        int rc = ensure(h, h->sc[h->cur].mods, (size_t)h->L * B * h->H * sizeof(float));
         if (rc) return rc;
-        mods = (float*)h->ws_mods.p;
+        mods = (float*)h->sc[h->cur].mods.p;
     }
     int rc = launch_modulator(h, z_dev, B, mods);
     if (rc) return rc;
@@ -606,11 +613,22 @@ int forward_latent_dev(msiren_ctx* h, const float* z_dev, int64_t B, float* out_
 }
 
 int forward_tiles_dev(msiren_ctx* h, const float* tiles_dev, int64_t B, float* out_dev) {
-    int rc = ensure(h, h->ws_latent, (size_t)B * h->Z * sizeof(float));
+    int rc = ensure(h, h->sc[h->cur].latent, (size_t)B * h->Z * sizeof(float));
     if (rc) return rc;
-    rc = launch_encoder(h, tiles_dev, B, (float*)h->ws_latent.p);
+    rc = launch_encoder(h, tiles_dev, B, (float*)h->sc[h->cur].latent.p);
     if (rc) return rc;
-    return forward_latent_dev(h, (const float*)h->ws_latent.p, B, out_dev, nullptr);
+    return forward_latent_dev(h, (const float*)h->sc[h->cur].latent.p, B, out_dev, nullptr);
+}
+
+int sync_all(msiren_ctx* h) {
+    for (auto& c : h->sc)
+        if (c.s) HIPCHK(hipStreamSynchronize(c.s));
+    return 0;
+}
+
+// asynchronous forward entry points rotate over the configured streams
+void next_stream(msiren_ctx* h) {
+    if (h->nstreams > 1) h->cur ^= 1;
 }
 
 int check(msiren_ctx* h, bool need_commit = true) {
@@ -672,7 +690,8 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     h->num_cus = prop.multiProcessorCount;
     declare_expected(h);
     hipError_t e = hipSetDevice(cfg->device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->sc[0].s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->sc[1].s, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -686,12 +705,15 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
 int msiren_destroy(msiren_handle h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& c : h->sc)
+        if (c.s) (void)hipStreamSynchronize(c.s);
     if (h->d_wp16) (void)hipFree(h->d_wp16);
     float* ptrs[] = {h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
-    DevBuf* bufs[] = {&h->ws_mods, &h->ws_modpad, &h->ws_out, &h->ws_latent, &h->ws_tiles, &h->ws_in, &h->ws_patches, &h->ws_keep, &h->ws_rec, &h->ws_img};
+    DevBuf* bufs[] = {&h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
+                      &h->sc[0].patches, &h->sc[0].keep, &h->sc[0].rec, &h->sc[1].mods, &h->sc[1].modpad, &h->sc[1].latent,
+                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& pr : h->prof_events) {
@@ -700,7 +722,8 @@ int msiren_destroy(msiren_handle h) {
     }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (auto& c : h->sc)
+        if (c.s) (void)hipStreamDestroy(c.s);
     delete h;
     return 0;
 }
@@ -719,7 +742,7 @@ int msiren_set_tensor(msiren_handle h, const char* name, const float* host_data,
 int msiren_commit_weights(msiren_handle h) {
     int rc = check(h, false);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = sync_all(h))) return rc;
     if ((rc = pack_trunk(h))) return rc;
     if ((rc = pack_trunk_f16x3(h))) return rc;
     if ((rc = pack_fold_weights(h))) return rc;
@@ -736,6 +759,7 @@ int msiren_commit_weights(msiren_handle h) {
 int msiren_forward_mods_dev(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev) {
     int rc = check(h);
     if (rc) return rc;
+    next_stream(h);
     if (B < 0 || (B > 0 && (!mods_dev || !out_dev))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
     return launch_trunk(h, mods_dev, B, out_dev);
 }
@@ -746,17 +770,18 @@ int msiren_forward_mods(msiren_handle h, const float* mods_host, int64_t B, floa
     if (B < 0 || (B > 0 && (!mods_host || !out_host))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
     if (B == 0) return 0;
     const size_t nm = (size_t)h->L * B * h->H * sizeof(float), no = (size_t)B * h->P * sizeof(float);
-    if ((rc = ensure(h, h->ws_mods, nm)) || (rc = ensure(h, h->ws_out, no))) return rc;
-    HIPCHK(hipMemcpyAsync(h->ws_mods.p, mods_host, nm, hipMemcpyHostToDevice, h->stream));
-    if ((rc = launch_trunk(h, (const float*)h->ws_mods.p, B, (float*)h->ws_out.p))) return rc;
-    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = ensure(h, h->sc[h->cur].mods, nm)) || (rc = ensure(h, h->ws_out, no))) return rc;
+    HIPCHK(hipMemcpyAsync(h->sc[h->cur].mods.p, mods_host, nm, hipMemcpyHostToDevice, h->sc[h->cur].s));
+    if ((rc = launch_trunk(h, (const float*)h->sc[h->cur].mods.p, B, (float*)h->ws_out.p))) return rc;
+    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
     return 0;
 }
 
 int msiren_forward_latent_dev(msiren_handle h, const float* z_dev, int64_t B, float* out_dev, float* mods_out_dev) {
     int rc = check(h);
     if (rc) return rc;
+    next_stream(h);
     if (B < 0 || (B > 0 && (!z_dev || !out_dev))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
     return forward_latent_dev(h, z_dev, B, out_dev, mods_out_dev);
 }
@@ -768,18 +793,19 @@ int msiren_forward_latent(msiren_handle h, const float* z_host, int64_t B, float
     if (B == 0) return 0;
     const size_t nz = (size_t)B * h->Z * sizeof(float), no = (size_t)B * h->P * sizeof(float);
     const size_t nm = (size_t)h->L * B * h->H * sizeof(float);
-    if ((rc = ensure(h, h->ws_latent, nz)) || (rc = ensure(h, h->ws_out, no)) || (rc = ensure(h, h->ws_mods, nm))) return rc;
-    HIPCHK(hipMemcpyAsync(h->ws_latent.p, z_host, nz, hipMemcpyHostToDevice, h->stream));
-    if ((rc = forward_latent_dev(h, (const float*)h->ws_latent.p, B, (float*)h->ws_out.p, (float*)h->ws_mods.p))) return rc;
-    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->stream));
-    if (mods_out_host) HIPCHK(hipMemcpyAsync(mods_out_host, h->ws_mods.p, nm, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = ensure(h, h->sc[h->cur].latent, nz)) || (rc = ensure(h, h->ws_out, no)) || (rc = ensure(h, h->sc[h->cur].mods, nm))) return rc;
+    HIPCHK(hipMemcpyAsync(h->sc[h->cur].latent.p, z_host, nz, hipMemcpyHostToDevice, h->sc[h->cur].s));
+    if ((rc = forward_latent_dev(h, (const float*)h->sc[h->cur].latent.p, B, (float*)h->ws_out.p, (float*)h->sc[h->cur].mods.p))) return rc;
+    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    if (mods_out_host) HIPCHK(hipMemcpyAsync(mods_out_host, h->sc[h->cur].mods.p, nm, hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
     return 0;
 }
 
 int msiren_forward_tiles_dev(msiren_handle h, const float* tiles_dev, int64_t B, float* out_dev) {
     int rc = check(h);
     if (rc) return rc;
+    next_stream(h);
     if (B < 0 || (B > 0 && (!tiles_dev || !out_dev))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
     if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles (siren_encoder.py:499), outer_patch_size=%d", h->O);
     return forward_tiles_dev(h, tiles_dev, B, out_dev);
@@ -793,10 +819,10 @@ int msiren_forward_tiles(msiren_handle h, const float* tiles_host, int64_t B, fl
     if (B == 0) return 0;
     const size_t nt = (size_t)B * h->O * h->O * sizeof(float), no = (size_t)B * h->P * sizeof(float);
     if ((rc = ensure(h, h->ws_tiles, nt)) || (rc = ensure(h, h->ws_out, no))) return rc;
-    HIPCHK(hipMemcpyAsync(h->ws_tiles.p, tiles_host, nt, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ws_tiles.p, tiles_host, nt, hipMemcpyHostToDevice, h->sc[h->cur].s));
     if ((rc = forward_tiles_dev(h, (const float*)h->ws_tiles.p, B, (float*)h->ws_out.p))) return rc;
-    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
     return 0;
 }
 
@@ -820,7 +846,7 @@ int msiren_image_to_patches_dev(msiren_handle h, const float* images_dev, int64_
         return fail(MSIREN_E_INVALID, "image %dx%d is too small for reflect padding of %d/%d", height, width, pad + vpad, pad + hpad);
     const int nV = (height + vpad) / h->I, nH = (width + hpad) / h->I;
     const int64_t total = n * nV * nH * h->O * h->O;
-    hipLaunchKernelGGL(msiren::image_to_patches_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(msiren::image_to_patches_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->sc[h->cur].s,
                        images_dev, patches_dev, n, height, width, nV, nH, h->O, h->I, pad);
     HIPCHK(hipGetLastError());
     return 0;
@@ -832,7 +858,7 @@ int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev, int64_t n,
     if (n < 0 || nV < 1 || nH < 1) return fail(MSIREN_E_INVALID, "bad arguments");
     if (n == 0) return 0;
     const int64_t total = n * nV * h->I * (int64_t)nH * h->I;
-    hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->sc[h->cur].s,
                        tiles_dev, h->d_foldw, recon_dev, nullptr, n, nV, nH, h->S, h->I, (h->S - h->I) / 2);
     HIPCHK(hipGetLastError());
     return 0;
@@ -841,31 +867,32 @@ int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev, int64_t n,
 int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int64_t n, int32_t height, int32_t width, float* recon_dev) {
     int rc = check(h);
     if (rc) return rc;
+    next_stream(h);
     if (n < 0 || (n > 0 && (!images_dev || !recon_dev))) return fail(MSIREN_E_INVALID, "bad arguments");
     if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles, outer_patch_size=%d", h->O);
     if (n == 0) return 0;
     int32_t nV, nH;
     if ((rc = msiren_recon_shape(h, height, width, &nV, &nH))) return rc;
     const int64_t NP = n * nV * nH;
-    if ((rc = ensure(h, h->ws_patches, (size_t)NP * h->O * h->O * sizeof(float)))) return rc;
-    if ((rc = ensure(h, h->ws_keep, (size_t)(NP + 64) * sizeof(int)))) return rc;
-    if ((rc = ensure(h, h->ws_rec, (size_t)NP * h->P * sizeof(float)))) return rc;
-    if ((rc = ensure(h, h->ws_latent, (size_t)NP * h->Z * sizeof(float)))) return rc;
-    if ((rc = ensure(h, h->ws_mods, (size_t)h->L * NP * h->H * sizeof(float)))) return rc;
-    float* patches = (float*)h->ws_patches.p;
-    int* black = (int*)h->ws_keep.p;
-    float* rec = (float*)h->ws_rec.p;
+    if ((rc = ensure(h, h->sc[h->cur].patches, (size_t)NP * h->O * h->O * sizeof(float)))) return rc;
+    if ((rc = ensure(h, h->sc[h->cur].keep, (size_t)(NP + 64) * sizeof(int)))) return rc;
+    if ((rc = ensure(h, h->sc[h->cur].rec, (size_t)NP * h->P * sizeof(float)))) return rc;
+    if ((rc = ensure(h, h->sc[h->cur].latent, (size_t)NP * h->Z * sizeof(float)))) return rc;
+    if ((rc = ensure(h, h->sc[h->cur].mods, (size_t)h->L * NP * h->H * sizeof(float)))) return rc;
+    float* patches = (float*)h->sc[h->cur].patches.p;
+    int* black = (int*)h->sc[h->cur].keep.p;
+    float* rec = (float*)h->sc[h->cur].rec.p;
     if ((rc = msiren_image_to_patches_dev(h, images_dev, n, height, width, patches))) return rc;
     // The reference compacts the non-black tiles, runs the model, and scatters zeros back
     // (tiling.py:244-303).  Patches are independent, so evaluating all of them in place and
     // zeroing the black ones in the fold gives identical results without a device-side compaction.
-    hipLaunchKernelGGL(msiren::black_flags_kernel, dim3((unsigned)NP), dim3(256), 0, h->stream, patches, black, h->O * h->O);
+    hipLaunchKernelGGL(msiren::black_flags_kernel, dim3((unsigned)NP), dim3(256), 0, h->sc[h->cur].s, patches, black, h->O * h->O);
     HIPCHK(hipGetLastError());
-    if ((rc = launch_encoder(h, patches, NP, (float*)h->ws_latent.p))) return rc;
-    if ((rc = launch_modulator(h, (const float*)h->ws_latent.p, NP, (float*)h->ws_mods.p))) return rc;
-    if ((rc = launch_trunk(h, (const float*)h->ws_mods.p, NP, rec))) return rc;
+    if ((rc = launch_encoder(h, patches, NP, (float*)h->sc[h->cur].latent.p))) return rc;
+    if ((rc = launch_modulator(h, (const float*)h->sc[h->cur].latent.p, NP, (float*)h->sc[h->cur].mods.p))) return rc;
+    if ((rc = launch_trunk(h, (const float*)h->sc[h->cur].mods.p, NP, rec))) return rc;
     const int64_t total = n * nV * h->I * (int64_t)nH * h->I;
-    hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->sc[h->cur].s,
                        rec, h->d_foldw, recon_dev, black, n, nV, nH, h->S, h->I, (h->S - h->I) / 2);
     HIPCHK(hipGetLastError());
     return 0;
@@ -881,17 +908,27 @@ int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t
     const size_t ni = (size_t)n * height * width * sizeof(float);
     const size_t nr = (size_t)n * nV * h->I * nH * h->I * sizeof(float);
     if ((rc = ensure(h, h->ws_in, ni)) || (rc = ensure(h, h->ws_img, nr))) return rc;
-    HIPCHK(hipMemcpyAsync(h->ws_in.p, images_host, ni, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ws_in.p, images_host, ni, hipMemcpyHostToDevice, h->sc[h->cur].s));
     if ((rc = msiren_reconstruct_slices_dev(h, (const float*)h->ws_in.p, n, height, width, (float*)h->ws_img.p))) return rc;
-    HIPCHK(hipMemcpyAsync(recon_host, h->ws_img.p, nr, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(recon_host, h->ws_img.p, nr, hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
+    return 0;
+}
+
+int msiren_set_streams(msiren_handle h, int32_t n) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (n != 1 && n != 2) return fail(MSIREN_E_INVALID, "streams must be 1 or 2, got %d", n);
+    if ((rc = sync_all(h))) return rc;
+    h->nstreams = n;
+    h->cur = 0;
     return 0;
 }
 
 int msiren_sync(msiren_handle h) {
     int rc = check(h, false);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = sync_all(h))) return rc;
     return 0;
 }
 
@@ -909,7 +946,7 @@ int msiren_dev_free(msiren_handle h, void* dev_ptr) {
     int rc = check(h, false);
     if (rc) return rc;
     if (dev_ptr) {
-        HIPCHK(hipStreamSynchronize(h->stream));
+        if ((rc = sync_all(h))) return rc;
         HIPCHK(hipFree(dev_ptr));
     }
     return 0;
@@ -919,8 +956,9 @@ int msiren_memcpy_h2d(msiren_handle h, void* dst_dev, const void* src_host, size
     int rc = check(h, false);
     if (rc) return rc;
     if (bytes == 0) return 0;
-    HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = sync_all(h))) return rc;
+    HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, h->sc[h->cur].s));
+    HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
     return 0;
 }
 
@@ -928,22 +966,25 @@ int msiren_memcpy_d2h(msiren_handle h, void* dst_host, const void* src_dev, size
     int rc = check(h, false);
     if (rc) return rc;
     if (bytes == 0) return 0;
-    HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = sync_all(h))) return rc;
+    HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
     return 0;
 }
 
 int msiren_timer_start(msiren_handle h) {
     int rc = check(h, false);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    if ((rc = sync_all(h))) return rc;
+    HIPCHK(hipEventRecord(h->ev0, h->sc[0].s));
     return 0;
 }
 
 int msiren_timer_stop(msiren_handle h, float* elapsed_ms) {
     int rc = check(h, false);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    if ((rc = sync_all(h))) return rc;
+    HIPCHK(hipEventRecord(h->ev1, h->sc[0].s));
     HIPCHK(hipEventSynchronize(h->ev1));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -954,7 +995,7 @@ int msiren_timer_stop(msiren_handle h, float* elapsed_ms) {
 int msiren_profile_enable(msiren_handle h, int32_t on) {
     int rc = check(h, false);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = sync_all(h))) return rc;
     h->profile = on != 0;
     h->prof_used = 0;
     h->prof_launches = 0;
@@ -965,7 +1006,7 @@ int msiren_profile_enable(msiren_handle h, int32_t on) {
 int msiren_profile_read(msiren_handle h, int64_t* launches, double* trunk_ms_total) {
     int rc = check(h, false);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = sync_all(h))) return rc;
     for (size_t i = 0; i < h->prof_used; ++i) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, h->prof_events[i].first, h->prof_events[i].second));
@@ -1002,13 +1043,13 @@ int msiren_trunk_timeline(msiren_handle h, const float* mods_dev, int64_t B, flo
     const int grid = (int)(B * chunks);
     DevBuf st;
     if ((rc = ensure(h, st, (size_t)grid * 32 * sizeof(uint64_t)))) return rc;
-    HIPCHK(hipMemsetAsync(st.p, 0, (size_t)grid * 32 * sizeof(uint64_t), h->stream));
+    HIPCHK(hipMemsetAsync(st.p, 0, (size_t)grid * 32 * sizeof(uint64_t), h->sc[h->cur].s));
     msiren::TrunkParams p = make_trunk_params(h, mods_dev, h->H, B, out_dev);
     p.stamps = (unsigned long long*)st.p;
-    hipLaunchKernelGGL((msiren::siren_trunk_f32_kernel<256, 0, 0, 1>), dim3(grid), dim3(256), 256 * 256 + 256 * 16, h->stream, p);
+    hipLaunchKernelGGL((msiren::siren_trunk_f32_kernel<256, 0, 0, 1>), dim3(grid), dim3(256), 256 * 256 + 256 * 16, h->sc[h->cur].s, p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(stamps_host, st.p, (size_t)grid * 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(stamps_host, st.p, (size_t)grid * 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
     HIPCHK(hipFree(st.p));
     return 0;
 }
