@@ -175,6 +175,21 @@ def main():
     _lib.check(lib.msiren_profile_read(h, C.byref(launches), C.byref(trunk_ms)))
     _lib.check(lib.msiren_profile_enable(h, 0))
     elapsed = t1 - t0
+    overlapped_trunk_ms = trunk_ms.value / max(launches.value, 1)
+    n_over = int(launches.value)
+    if args.streams > 1:
+        # With two streams the launches of consecutive steps overlap, so a launch's own duration says
+        # little about the kernel.  The roofline figure is therefore taken from a short single-stream
+        # phase of the same process (kernel alone on the device), after the timed region.
+        _lib.check(lib.msiren_set_streams(h, 1))
+        for _ in range(3):
+            step()
+        model.sync()
+        _lib.check(lib.msiren_profile_enable(h, 1))
+        for _ in range(max(10, args.steps // 4)):
+            step()
+        _lib.check(lib.msiren_profile_read(h, C.byref(launches), C.byref(trunk_ms)))
+        _lib.check(lib.msiren_profile_enable(h, 0))
     if world > 1:
         dist.barrier()
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -213,6 +228,10 @@ def main():
             "frac": achieved / peak, "traffic": None, "kernel": kernel,
             "flops_per_launch": flops_launch, "avg_launch_ms": trunk_avg_s * 1e3, "launches": int(launches.value),
             "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+            "measured": "HIP event pairs on the kernel's stream; single-stream phase of this run (kernel alone)"
+                        if args.streams > 1 else "HIP event pairs on the kernel's stream inside the timed region",
+            "timed_region_avg_launch_ms": overlapped_trunk_ms, "timed_region_launches": n_over,
+            "pipelined_tflops": flops_launch * world * args.steps / elapsed / 1e12 / world,
             "note": "achieved = algorithmic FLOPs (525824 per coordinate) / mean kernel time; for f16x3 the "
                     "kernel issues 3x that many fp16 MFMA FLOPs, hence peak = 2500/3",
         },

@@ -58,7 +58,7 @@ struct msiren_ctx {
     // overlaps the encoder / modulator / trunk start of the next call.
     struct StreamCtx {
         hipStream_t s = nullptr;
-        DevBuf mods, modpad, latent, patches, keep, rec;
+        DevBuf mods, modpad, latent, patches, keep, rec, queue;
     } sc[2];
     int cur = 0, nstreams = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -474,7 +474,17 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     p.dbg_flags = 0;
     if (const char* e = std::getenv("MSIREN_F16_FLAGS")) p.dbg_flags = std::atoi(e);
     const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
-    if (msiren::F16Lds<4>::total(h->L) <= 160 * 1024) return launch_trunk_f16x3_r<4>(h, p, grid);
+    {   // pass queue: workgroup g starts with pass g, further passes come from this counter
+        int rc = ensure(h, h->sc[h->cur].queue, 256);
+        if (rc) return rc;
+        p.pass_counter = (int*)h->sc[h->cur].queue.p;
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p.pass_counter, grid, 1, h->sc[h->cur].s));
+    }
+    // R = 3 leaves ~35 KB of LDS per CU free, enough for an encoder / modulator workgroup of the NEXT
+    // call (other stream) to run beside the persistent trunk workgroup; R = 4 fills the CU.
+    int ring = h->nstreams > 1 ? 3 : 4;
+    if (const char* e = std::getenv("MSIREN_F16_RING")) ring = std::atoi(e);
+    if (ring >= 4 && msiren::F16Lds<4>::total(h->L) <= 160 * 1024) return launch_trunk_f16x3_r<4>(h, p, grid);
     return launch_trunk_f16x3_r<3>(h, p, grid);
 }
 
@@ -713,7 +723,7 @@ int msiren_destroy(msiren_handle h) {
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
                       &h->sc[0].patches, &h->sc[0].keep, &h->sc[0].rec, &h->sc[1].mods, &h->sc[1].modpad, &h->sc[1].latent,
-                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec};
+                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec, &h->sc[0].queue, &h->sc[1].queue};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& pr : h->prof_events) {

@@ -44,6 +44,7 @@ struct TrunkF16Params {
     float winv[16];           // per hidden layer: exact inverse of the power-of-two weight scale
     float bout, cg0, cg;
     int B, P, L, units_per_patch, total_units;
+    int* pass_counter;        // work queue: next pass id; the host sets it to gridDim.x before every launch
     int dbg_flags;            // experiment knobs (MSIREN_F16_FLAGS): 1 = skip the weight DMA (timing only, wrong results)
 };
 
@@ -57,7 +58,8 @@ struct F16Lds {  // byte offsets into dynamic LDS
     static constexpr int zero = wout + 1024;        // 256 floats of 0 (stand-in for wout on non-final layers)
     static constexpr int bias = zero + 1024;        // (L-1) x 256 floats
     static __host__ __device__ constexpr int mods(int L) { return bias + (L - 1) * 1024; }  // 4 waves x L x 256 floats
-    static __host__ __device__ constexpr int total(int L) { return mods(L) + 4 * L * 1024; }
+    static __host__ __device__ constexpr int queue(int L) { return mods(L) + 4 * L * 1024; }  // 2 ints: next pass id
+    static __host__ __device__ constexpr int total(int L) { return queue(L) + 16; }
 };
 
 __device__ __forceinline__ h8 pack_h8(fp16x2 a, fp16x2 b, fp16x2 c, fp16x2 d) {
@@ -137,10 +139,11 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
 
     // ---- weight ring ---------------------------------------------------------------------------------
     // chunk sequence number `cg` counts tiles consumed by this workgroup; chunk id = cg mod nchunks.
-    const int G = gridDim.x;
-    const int upp = 4 * G;  // units per pass over the whole grid
-    const int npass = (p.total_units - 4 * (int)blockIdx.x + upp - 1) / upp;  // passes of THIS workgroup (>= 0)
-    const int total_chunks = npass * nchunks;
+    // Passes (4 units each) are handed out through a device-wide counter, not by a fixed stride: with two
+    // launches in flight on different streams a workgroup may start late on a CU the previous launch has
+    // just released, and then simply takes fewer passes -- every CU stays busy until the queue is empty.
+    volatile int* qslot = reinterpret_cast<volatile int*>(smem + LY::queue(L));
+    int cur_pass = (int)blockIdx.x;
     // each wave moves its 8 KB slice of a chunk: 8 x 1 KB global_load_lds_dwordx4, one base address
     // pair (biased by +4 KB so that the eight 1 KB steps fit the 13-bit signed immediate, which the
     // instruction applies to the global AND the LDS address)
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         dma_id = dma_id + 1 == nchunks ? 0 : dma_id + 1;
         dma_buf = dma_buf + 1 == R ? 0 : dma_buf + 1;
     };
-    if (npass <= 0) return;
+    if (cur_pass * 4 >= p.total_units) return;
 #pragma unroll
     for (int s = 0; s < R - 1; ++s) dma_next();
 
@@ -340,8 +343,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         wf_[0][3] = r0[3 * 64];
     }
 
-    for (int pass = 0; pass < npass; ++pass) {
-        int unit = (pass * G + (int)blockIdx.x) * 4 + wave;
+    for (int pass = 0; cur_pass * 4 < p.total_units; ++pass) {
+        int unit = cur_pass * 4 + wave;
         const bool active = unit < p.total_units;
         unit = active ? unit : p.total_units - 1;
         const int b = unit / p.units_per_patch;
@@ -350,11 +353,15 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         const bool pvalid = active && pc < p.P;
         pc = pc < p.P ? pc : p.P - 1;
 
+        // the next pass id is fetched a whole pass ahead, together with the loads below (one wait)
+        int nxt = 0;
+        if (tid == 0) nxt = atomicAdd(p.pass_counter, 1);
         // this wave's modulation table: (L, 256) floats of patch b
         for (int l = 0; l < L; ++l) {
             const f32x4 m = *reinterpret_cast<const f32x4*>(p.mods + ((size_t)l * p.B + b) * 256 + lane * 4);
             *reinterpret_cast<f32x4*>(modT + l * 256 + lane * 4) = m;
         }
+        if (tid == 0) qslot[(pass + 1) & 1] = nxt;  // read after >= 32 workgroup barriers
         const float2 xy = reinterpret_cast<const float2*>(p.grid)[pc];
 
         // ---- layer 0 (K = 2) directly in B-operand order: element j of k-step s is feature
@@ -407,6 +414,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         }
         part += __shfl_xor(part, 32);
         if (pvalid && half == 0) p.out[(size_t)b * p.P + pc] = sin_rev(part + p.bout);
+        cur_pass = __builtin_amdgcn_readfirstlane(qslot[(pass + 1) & 1]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may be in flight when the LDS is released
 #undef MSIREN_F16_LAYER

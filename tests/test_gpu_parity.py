@@ -260,3 +260,24 @@ def test_f16x3_full_forward_matches_fp32_path():
     ref = orc.modulated_siren_forward(sd, tiles, num_layers=5, dtype=np.float64)
     assert nerr(a, ref) < 1e-4 and nerr(b, ref) < 1e-4
     assert nerr(b, a) < 5e-5
+
+
+def test_two_stream_pipelining_is_bit_identical():
+    """msiren_set_streams(2): consecutive async calls alternate streams; results must not change."""
+    from mri_inr_amd import _lib
+
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    for prec in ("fp32", "f16x3"):
+        m = make_model(sd, precision=prec)
+        tiles = [np.random.default_rng(s).random((37 + 11 * s, 32, 32), dtype=np.float32) for s in range(6)]
+        ref = [m(t) for t in tiles]
+        d_in = [m.device_array(t.shape).copy_from(t) for t in tiles]
+        d_out = [m.device_array((t.shape[0], 24, 24)) for t in tiles]
+        _lib.check(m._lib.msiren_set_streams(m._h, 2))
+        for _ in range(3):
+            for a, b, t in zip(d_in, d_out, tiles):
+                _lib.check(m._lib.msiren_forward_tiles_dev(m._h, a.ptr, t.shape[0], b.ptr))
+        m.sync()
+        for r, b in zip(ref, d_out):
+            assert np.array_equal(r, b.numpy())
+        _lib.check(m._lib.msiren_set_streams(m._h, 1))
