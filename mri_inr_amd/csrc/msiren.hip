@@ -70,7 +70,7 @@ struct msiren_ctx {
     float bout = 0.f, cg0 = 0.f, cg = 0.f;
     // split-fp16 trunk (MSIREN_PREC_F16X3)
     void* d_wp16 = nullptr;
-    float *d_bias16 = nullptr, *d_wout16 = nullptr;
+    float *d_bias16 = nullptr, *d_wout16 = nullptr, *d_s0t = nullptr;
     float winv16[16] = {0};
     bool f16x3_ready = false;
     int num_cus = 256;
@@ -288,6 +288,25 @@ int pack_trunk_f16x3(msiren_ctx* h) {
     int rc;
     if ((rc = upload(&h->d_bias16, bias))) return rc;
     if ((rc = upload(&h->d_wout16, wout))) return rc;
+    {   // layer-0 activation table S0T[f/4][p][f%4] = act0(w0_initial * (W0 x_p + b0)), fp64 -> fp32
+        const auto& W0 = *get(h, "net.layers.0.weight");
+        const auto* B0 = h->cfg.use_bias ? get(h, "net.layers.0.bias") : nullptr;
+        std::vector<float> grid;
+        if (const auto* g = get(h, "grid")) grid = *g;
+        if (grid.size() != (size_t)h->P * 2) return fail(MSIREN_E_STATE, "grid buffer missing");
+        std::vector<float> tab((size_t)64 * h->P * 4);
+        const bool morlet = h->cfg.activation == MSIREN_ACT_MORLET;
+        for (int f = 0; f < 256; ++f)
+            for (int pidx = 0; pidx < h->P; ++pidx) {
+                // the pre-activation is formed in fp32 like F.linear does, the activation in fp64
+                const float pre = std::fmaf(grid[(size_t)pidx * 2 + 1], W0[(size_t)f * 2 + 1],
+                                            std::fmaf(grid[(size_t)pidx * 2], W0[(size_t)f * 2], B0 ? (*B0)[f] : 0.f));
+                double a = std::sin((double)h->cfg.w0_initial * (double)pre);
+                if (morlet) a *= std::exp(-0.5 * (double)pre * (double)pre);
+                tab[((size_t)(f / 4) * h->P + pidx) * 4 + (f & 3)] = (float)a;
+            }
+        if ((rc = upload(&h->d_s0t, tab))) return rc;
+    }
     h->f16x3_ready = true;
     return 0;
 }
@@ -455,6 +474,7 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     msiren::TrunkF16Params p{};
     p.grid = h->d_grid;
     p.l0 = h->d_l0;
+    p.s0t = h->d_s0t;
     p.wp = (const _Float16*)h->d_wp16;
     p.bias = h->d_bias16;
     p.wout = h->d_wout16;
@@ -718,7 +738,7 @@ int msiren_destroy(msiren_handle h) {
     for (auto& c : h->sc)
         if (c.s) (void)hipStreamSynchronize(c.s);
     if (h->d_wp16) (void)hipFree(h->d_wp16);
-    float* ptrs[] = {h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
+    float* ptrs[] = {h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,

@@ -36,6 +36,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct TrunkF16Params {
     const float* grid;        // (P,2)
     const float* l0;          // (256,4) {w_row, w_col, b, 0} * w0_initial/2pi
+    const float* s0t;         // (64, P, 4): layer-0 activations act0(W0 x_p + b0) before modulation, feature-group major
     const _Float16* wp;       // [(L-1)*8 chunks][16 k-steps][2: hi,lo][64 lanes][8]
     const float* bias;        // (L-1, 256) in revolutions
     const float* wout;        // (256) * w0/2pi
@@ -368,21 +369,26 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         //      32*(s>>1) + 16*(s&1) + 8*(j>>2) + 4*half + (j&3).  K-steps 0..13 are finished here; the
         //      last 32 features (k-steps 14, 15 = "tile 7") are left as sine ARGUMENTS in acc[1], where
         //      the first hidden layer's pending-epilogue slot turns them into X[14], X[15].
+        // The unmodulated layer-0 activations depend on the pixel only, not on the patch: they come from
+        // a table built once per weight set (fp64 on the host), so layer 0 costs one coalesced 16-byte
+        // load + 4 multiplies + the fp16 split per four features instead of 4 x (2 FMA + sine).
+        const f32x4* s0 = reinterpret_cast<const f32x4*>(p.s0t) + (size_t)half * p.P + pc;
+        f32x4 raw[14][2];  // all 28 loads in flight at once: one L2 latency per pass instead of seven
+#pragma unroll
+        for (int s = 0; s < 14; ++s)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int f0 = 32 * (s >> 1) + 16 * (s & 1) + 8 * q;  // + 4*half via the base
+                raw[s][q] = s0[(size_t)(f0 / 4) * p.P];
+            }
 #pragma unroll
         for (int s = 0; s < 14; ++s) {
             fp16x2 hh[2][2], ll[2][2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int f0 = 32 * (s >> 1) + 16 * (s & 1) + 8 * q;  // + 4*half, carried by the bases
+                const int f0 = 32 * (s >> 1) + 16 * (s & 1) + 8 * q;
                 const f32x4 m4 = *reinterpret_cast<const f32x4*>(modB + f0 * 4);
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(l0B + (f0 + e) * 16);
-                    const float r = __builtin_fmaf(xy.y, w[1], __builtin_fmaf(xy.x, w[0], w[2]));
-                    v[e] = activate<ACT>(r, p.cg0) * m4[e];
-                }
-                split4(v, hh[q][0], hh[q][1], ll[q][0], ll[q][1]);
+                split4(raw[s][q] * m4, hh[q][0], hh[q][1], ll[q][0], ll[q][1]);
             }
             Xh[s] = to_acc_file(pack_h8(hh[0][0], hh[0][1], hh[1][0], hh[1][1]));
             Xl[s] = to_acc_file(pack_h8(ll[0][0], ll[0][1], ll[1][0], ll[1][1]));
