@@ -71,6 +71,17 @@ def effective_cores() -> int:
     return max(1, min(n, 16))
 
 
+def traffic_bytes(kernel):
+    """HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes (collected with
+    tools/profile.sh: separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction); None if the
+    profile on record is for another kernel."""
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "r1", "traffic.json")))
+        return d["bytes_per_launch"] if d.get("kernel") == kernel else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(sd, tiles, activation, budget_s):
     """The torch-CPU twin (oracle/torch_twin.py, "port") timed on this box's host cores."""
     import torch
@@ -225,7 +236,7 @@ def main():
         },
         "roofline": {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": None, "kernel": kernel,
+            "frac": achieved / peak, "traffic": traffic_bytes(kernel), "kernel": kernel,
             "flops_per_launch": flops_launch, "avg_launch_ms": trunk_avg_s * 1e3, "launches": int(launches.value),
             "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
             "measured": "HIP event pairs on the kernel's stream; single-stream phase of this run (kernel alone)"

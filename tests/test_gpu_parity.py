@@ -281,3 +281,24 @@ def test_two_stream_pipelining_is_bit_identical():
         for r, b in zip(ref, d_out):
             assert np.array_equal(r, b.numpy())
         _lib.check(m._lib.msiren_set_streams(m._h, 1))
+
+
+@pytest.mark.parametrize("H,L,Z,act", [(512, 10, 128, "sine"), (256, 4, 64, "morlet")])
+def test_residual_variant_vs_own_oracle(H, L, Z, act):
+    """BASELINE config 5 shape (10 x 512, latent 128) with the build-defined residual semantics
+    x_{l+1} = x_l + mod_l * act(W_l x_l + b_l), l >= 1.  PARITY UNPINNED against the reference (its
+    residual branch is not in the container): checked against this build's own oracle only."""
+    sd = syn.make_state_dict(seed=21, dim_hidden=H, num_layers=L, latent_dim=Z, siren_patch_size=24, with_encoder=False)
+    sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
+    m = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda", activation=act,
+                       residual=True)
+    m.load_state_dict(sd, strict=False)
+    m.to("cuda")
+    mods = syn.make_mods(8, L, 6, H, lo=0.1, hi=0.6)
+    out = m.forward_mods(mods)
+    ref = orc.siren_forward(sd, mods, num_layers=L, activation=act, residual=True, dtype=np.float64)
+    ref32 = orc.siren_forward(sd, mods, num_layers=L, activation=act, residual=True)
+    e = nerr(out.reshape(6, -1), ref)
+    assert e <= max(1e-4, 10 * nerr(ref32, ref)), (e, nerr(ref32, ref))
