@@ -125,14 +125,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (the HIP path has no CPU fallback)")
+    # one rank per GPU; MSIREN_BENCH_BACKEND=gloo lets several ranks share one card (rehearsal of the
+    # N > 1 code path on a 1-GPU box: RCCL refuses two ranks on the same device)
+    backend = os.environ.get("MSIREN_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- model: random-init weights of the named architecture; rank 0's copy is broadcast (RCCL) ----
     sd = syn.make_state_dict(seed=7, trained_like=True) if rank == 0 else None
-    sd = broadcast_state_dict(sd, src=0, device=torch.device("cuda", local_rank)) if world > 1 else sd
+    if world > 1:
+        sd = broadcast_state_dict(sd, src=0, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
     model = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
                            use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
                            outer_patch_size=32, inner_patch_size=16, siren_patch_size=24,
@@ -203,7 +211,7 @@ def main():
         _lib.check(lib.msiren_profile_enable(h, 0))
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
