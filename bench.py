@@ -39,7 +39,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--slices", type=int, default=1, help="320x320 slices per GPU per step")
     ap.add_argument("--activation", default="sine", choices=["sine", "morlet"])
-    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3"],
+    ap.add_argument("--model", default="baseline", choices=["baseline", "deep_residual"],
+                    help="baseline = 5 x 256 (BASELINE configs 1-4); deep_residual = 10 x 512, latent 128, residual "
+                         "(config 5; own semantics, precision defaults to bf16)")
+    ap.add_argument("--precision", default=None, choices=["fp32", "f16x3", "bf16", "f16"],
                     help="trunk arithmetic: f16x3 = split-fp16, 3 f16 MFMAs per product, fp32-equivalent accuracy "
                          "(default); fp32 = v_mfma_f32_32x32x2_f32")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
@@ -92,7 +95,7 @@ def cpu_baseline(sd, tiles, activation, budget_s):
     torch.set_num_threads(cores)
     t = tw.to_tensors(sd)
     x = torch.from_numpy(tiles)
-    tw.forward_tiles(t, x[:64], num_layers=5, activation=activation)  # warm-up
+    tw.forward_tiles(t, x[:64], num_layers=5, activation=activation)  # warm-up (baseline model only)
     n, t0 = 0, time.perf_counter()
     while True:
         tw.forward_tiles(t, x, num_layers=5, activation=activation)
@@ -110,6 +113,10 @@ def cpu_baseline(sd, tiles, activation, budget_s):
 
 def main():
     args = parse()
+    deep = args.model == "deep_residual"
+    if args.precision is None:
+        args.precision = "bf16" if deep else "f16x3"
+    H, L, Z = (512, 10, 128) if deep else (256, 5, 256)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,13 +145,16 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- model: random-init weights of the named architecture; rank 0's copy is broadcast (RCCL) ----
-    sd = syn.make_state_dict(seed=7, trained_like=True) if rank == 0 else None
+    # deep residual model: modulations centred on 0.25 keep the 10-layer residual stream in the regime
+    # where 16-bit operands are meaningful (with O(1) modulations it is chaotic: even fp32 is only 2e-4)
+    kw = dict(modulator_bias_center=0.25, encoder_gain=10.0) if deep else dict(trained_like=True)
+    sd = syn.make_state_dict(seed=7, dim_hidden=H, num_layers=L, latent_dim=Z, **kw) if rank == 0 else None
     if world > 1:
         sd = broadcast_state_dict(sd, src=0, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
-    model = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
+    model = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=1.0, w0_initial=30.0,
                            use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
                            outer_patch_size=32, inner_patch_size=16, siren_patch_size=24,
-                           device=f"cuda:{local_rank}", activation=args.activation, precision=args.precision)
+                           device=f"cuda:{local_rank}", activation=args.activation, precision=args.precision, residual=deep)
     model.load_state_dict(sd)
     model.to(f"cuda:{local_rank}").eval()
     lib, h = model._lib, model._h
@@ -226,20 +236,23 @@ def main():
         # MFMA peak / 3.  The fp32-MFMA peak the north star names is reported next to it.
         dtype, peak = "f16x3 (split-fp16 MFMA, fp32 accumulate; fp32-equivalent accuracy)", F16_MFMA_PEAK_TFLOPS / 3.0
         kernel = "siren_trunk_f16x3_kernel<%d,4>" % (1 if args.activation == "morlet" else 0)
+    elif args.precision in ("bf16", "f16"):
+        dtype, peak = f"{args.precision} operands, fp32 accumulate", F16_MFMA_PEAK_TFLOPS
+        kernel = "siren_trunk_x1_kernel<%d,%d,%d,3>" % (args.precision == "bf16", args.activation == "morlet", deep)
     else:
         dtype, peak = "f32", FP32_MFMA_PEAK_TFLOPS
-        kernel = "siren_trunk_f32_kernel<256,%d,0,0>" % (1 if args.activation == "morlet" else 0)
+        kernel = "siren_trunk_f32_kernel<%d,%d,%d,0>" % (H, args.activation == "morlet", deep)
     result = {
         "metric": "Mpixels/sec reconstructed (320x320 slice, hidden=256, 5 layers)",
         "value": value, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[1]: {n_sl} x 320x320 slice per GPU per step -> {B} tiles 32x32 -> "
+            "workload": f"BASELINE configs[{4 if deep else 1}]{' (deep residual 10x512, own semantics)' if deep else ''}: {n_sl} x 320x320 slice per GPU per step -> {B} tiles 32x32 -> "
                         f"ModulatedSiren.forward (encoder+modulator+fused trunk, {args.activation}) -> {B}x24x24; "
                         "tiles and outputs resident in HBM",
             "slices_per_gpu_per_step": n_sl, "patches_per_step_per_gpu": B, "coords_per_patch": 576,
-            "dim_hidden": 256, "num_layers": 5, "activation": args.activation, "precision": args.precision, "streams": args.streams,
+            "dim_hidden": H, "num_layers": L, "latent_dim": Z, "residual": deep, "activation": args.activation, "precision": args.precision, "streams": args.streams,
             "parallelism": f"patch-shard x{world}",
         },
         "roofline": {
@@ -263,9 +276,12 @@ def main():
 
             got = d_out.numpy()[:64]
             tiles_h = d_tiles.numpy()[:64]
-            ref = orc.modulated_siren_forward(sd, tiles_h, num_layers=5, activation=args.activation, dtype=np.float64)
+            z = orc.encoder_forward(sd, tiles_h, dtype=np.float64)
+            mods = orc.modulator_forward(sd, z, num_layers=L, dtype=np.float64)
+            ref = orc.siren_forward(sd, mods, num_layers=L, activation=args.activation, residual=deep,
+                                    dtype=np.float64).reshape(-1, 24, 24)
             result["check_nerr_vs_fp64_oracle"] = float(np.abs(got - ref).max() / np.abs(ref).max())
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not deep:
             result["cpu_baseline"] = cpu_baseline(sd, d_tiles.numpy()[:400], args.activation, args.cpu_seconds)
         else:
             result["cpu_baseline"] = None

@@ -51,10 +51,12 @@ enum { MSIREN_ACT_SINE = 0, MSIREN_ACT_MORLET = 1 };
 /* arithmetic of the hidden-layer contractions */
 enum {
     MSIREN_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32, the parity path (configs 1-4) */
-    MSIREN_PREC_BF16 = 1, /* bf16 operands, fp32 accumulate (config 5; own tolerance)          */
-    MSIREN_PREC_F16X3 = 2 /* split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate;
+    MSIREN_PREC_BF16 = 1, /* bf16 operands, fp32 accumulate: register-resident single-product trunk,
+                             dim_hidden = 512, num_layers <= 12 (BASELINE config 5; own tolerance)  */
+    MSIREN_PREC_F16X3 = 2, /* split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate;
                              fp32-equivalent accuracy (22-bit operands); H = 256, 2 <= L <= 17.
                              Other shapes silently use MSIREN_PREC_F32.                          */
+    MSIREN_PREC_F16 = 3   /* as BF16 with fp16 operands (11-bit significand)                        */
 };
 
 /*

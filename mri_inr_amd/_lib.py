@@ -19,7 +19,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msiren.h")
 
 ABI_VERSION = 1
 ACT_SINE, ACT_MORLET = 0, 1
-PREC_F32, PREC_BF16, PREC_F16X3 = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
 E_INVALID, E_STATE, E_SHAPE, E_HIP, E_NOMEM = -1, -2, -3, -4, -5
 
 

@@ -20,6 +20,7 @@
 #include "encoder_modulator.hip.h"
 #include "siren_trunk_f16x3.hip.h"
 #include "siren_trunk_f32.hip.h"
+#include "siren_trunk_x1.hip.h"
 #include "tiling.hip.h"
 
 namespace {
@@ -73,6 +74,11 @@ struct msiren_ctx {
     float *d_bias16 = nullptr, *d_wout16 = nullptr, *d_s0t = nullptr;
     float winv16[16] = {0};
     bool f16x3_ready = false;
+    // single-product 16-bit trunk (MSIREN_PREC_BF16 / MSIREN_PREC_F16), H = 512
+    void *d_wpx1 = nullptr, *d_biasx1 = nullptr, *d_woutx1 = nullptr;
+    float *d_l0last = nullptr, *d_s0t512 = nullptr;
+    float winvx1[64] = {0};
+    bool x1_ready = false;
     int num_cus = 256;
     // modulator: transposed weights so that consecutive threads read consecutive outputs
     float *d_modw = nullptr, *d_modb = nullptr, *d_modw_rm = nullptr;  // transposed / as stored (row-major)
@@ -311,6 +317,84 @@ int pack_trunk_f16x3(msiren_ctx* h) {
     return 0;
 }
 
+// ---- single-product 16-bit trunk packing (H = 512) ---------------------------------------------
+uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+int pack_trunk_x1(msiren_ctx* h) {
+    h->x1_ready = false;
+    const int H = h->H, L = h->L;
+    const bool bf = h->cfg.precision == MSIREN_PREC_BF16;
+    if (!(h->cfg.precision == MSIREN_PREC_BF16 || h->cfg.precision == MSIREN_PREC_F16)) return 0;
+    if (H != 512 || L < 2 || L > 65 || msiren::X1Lds<3>::total(L) > 160 * 1024)
+        return fail(MSIREN_E_INVALID, "precision bf16/f16 (single-product register-resident trunk) needs dim_hidden = 512 and 2 <= num_layers <= 12; got H=%d L=%d", H, L);
+    const double two_pi = 6.283185307179586476925286766559;
+    const double c = (double)h->cfg.w0 / two_pi, c0 = (double)h->cfg.w0_initial / two_pi;
+    std::vector<uint16_t> wp((size_t)(L - 1) * 16 * 32 * 64 * 8), bias((size_t)(L - 1) * 512, 0), wout(512, 0);
+    for (int l = 1; l < L; ++l) {
+        const std::vector<float>& w = *get(h, "net.layers." + std::to_string(l) + ".weight");
+        int e = 0;
+        if (!bf) {  // fp16: scale max|W| into [8192, 16384); bf16 has fp32's exponent range
+            double mx = 0.0;
+            for (float v : w) mx = std::max(mx, std::fabs((double)v * c));
+            if (mx > 0.0) e = std::max(-14, std::min((int)std::floor(std::log2(16384.0 / mx)), 30));
+        }
+        const double sc = std::ldexp(c, e);
+        h->winvx1[l - 1] = (float)std::ldexp(1.0, -e);
+        for (int t = 0; t < 16; ++t)
+            for (int s = 0; s < 32; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int f = 32 * t + (lane & 31);
+                        const int k = 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+                        const float ws = (float)((double)w[(size_t)f * H + k] * sc);
+                        wp[((((size_t)(l - 1) * 16 + t) * 32 + s) * 64 + lane) * 8 + j] = bf ? f32_to_bf16_rne(ws) : f32_to_f16_rne(ws);
+                    }
+        if (const auto* b = h->cfg.use_bias ? get(h, "net.layers." + std::to_string(l) + ".bias") : nullptr)
+            for (int f = 0; f < H; ++f) bias[(size_t)(l - 1) * 512 + f] = f32_to_f16_rne((float)((double)(*b)[f] * c));
+    }
+    const auto* Wo = get(h, "net.last_layer.weight");
+    for (int f = 0; f < H; ++f) wout[f] = f32_to_f16_rne((float)((double)(*Wo)[f] * c));
+    const auto& W0 = *get(h, "net.layers.0.weight");
+    const auto* B0 = h->cfg.use_bias ? get(h, "net.layers.0.bias") : nullptr;
+    std::vector<float> l0last(32 * 4, 0.f);
+    for (int i = 0; i < 32; ++i) {
+        const int f = 480 + i;
+        l0last[i * 4 + 0] = (float)((double)W0[(size_t)f * 2 + 0] * c0);
+        l0last[i * 4 + 1] = (float)((double)W0[(size_t)f * 2 + 1] * c0);
+        l0last[i * 4 + 2] = B0 ? (float)((double)(*B0)[f] * c0) : 0.f;
+    }
+    const auto* g = get(h, "grid");
+    if (!g || g->size() != (size_t)h->P * 2) return fail(MSIREN_E_STATE, "grid buffer missing");
+    std::vector<float> tab((size_t)128 * h->P * 4);
+    const bool morlet = h->cfg.activation == MSIREN_ACT_MORLET;
+    for (int f = 0; f < 512; ++f)
+        for (int pidx = 0; pidx < h->P; ++pidx) {
+            const float pre = std::fmaf((*g)[(size_t)pidx * 2 + 1], W0[(size_t)f * 2 + 1],
+                                        std::fmaf((*g)[(size_t)pidx * 2], W0[(size_t)f * 2], B0 ? (*B0)[f] : 0.f));
+            double a = std::sin((double)h->cfg.w0_initial * (double)pre);
+            if (morlet) a *= std::exp(-0.5 * (double)pre * (double)pre);
+            tab[((size_t)(f / 4) * h->P + pidx) * 4 + (f & 3)] = (float)a;
+        }
+    auto up16 = [&](void** dst, const std::vector<uint16_t>& v) -> int {
+        if (*dst) HIPCHK(hipFree(*dst));
+        *dst = nullptr;
+        HIPCHK(hipMalloc(dst, v.size() * 2));
+        HIPCHK(hipMemcpy(*dst, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+        return 0;
+    };
+    int rc;
+    if ((rc = up16(&h->d_wpx1, wp)) || (rc = up16(&h->d_biasx1, bias)) || (rc = up16(&h->d_woutx1, wout))) return rc;
+    if ((rc = upload(&h->d_l0last, l0last)) || (rc = upload(&h->d_s0t512, tab))) return rc;
+    h->x1_ready = true;
+    return 0;
+}
+
 // ---- modulator / encoder packing ------------------------------------------------------------
 int pack_modulator(msiren_ctx* h) {
     const int H = h->H, Z = h->Z, L = h->L;
@@ -508,6 +592,52 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     return launch_trunk_f16x3_r<3>(h, p, grid);
 }
 
+int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
+    msiren::TrunkX1Params p{};
+    p.grid = h->d_grid;
+    p.l0last = h->d_l0last;
+    p.s0t = h->d_s0t512;
+    p.wp = (const unsigned short*)h->d_wpx1;
+    p.bias = (const _Float16*)h->d_biasx1;
+    p.wout = (const _Float16*)h->d_woutx1;
+    p.mods = mods_dev;
+    p.out = out_dev;
+    for (int i = 0; i < 64; ++i) p.winv[i] = h->winvx1[i];
+    p.bout = h->bout;
+    p.cg0 = h->cg0;
+    p.cg = h->cg;
+    p.B = (int)B;
+    p.P = h->P;
+    p.L = h->L;
+    p.units_per_patch = (h->P + 31) / 32;
+    const int64_t units = B * p.units_per_patch;
+    if (units > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
+    p.total_units = (int)units;
+    const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
+    int rc = ensure(h, h->sc[h->cur].queue, 256);
+    if (rc) return rc;
+    p.pass_counter = (int*)h->sc[h->cur].queue.p;
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p.pass_counter, grid, 1, h->sc[h->cur].s));
+    const int lds = msiren::X1Lds<3>::total(h->L);
+    const bool bf = h->cfg.precision == MSIREN_PREC_BF16, mor = h->cfg.activation == MSIREN_ACT_MORLET, res = h->cfg.residual != 0;
+#define MSIREN_X1_LAUNCH(BF, A, RS)                                                                  \
+    do {                                                                                             \
+        auto k = msiren::siren_trunk_x1_kernel<BF, A, RS, 3>;                                        \
+        HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);                       \
+    } while (0)
+    if (bf) {
+        if (mor) { if (res) MSIREN_X1_LAUNCH(1, 1, 1); else MSIREN_X1_LAUNCH(1, 1, 0); }
+        else     { if (res) MSIREN_X1_LAUNCH(1, 0, 1); else MSIREN_X1_LAUNCH(1, 0, 0); }
+    } else {
+        if (mor) { if (res) MSIREN_X1_LAUNCH(0, 1, 1); else MSIREN_X1_LAUNCH(0, 1, 0); }
+        else     { if (res) MSIREN_X1_LAUNCH(0, 0, 1); else MSIREN_X1_LAUNCH(0, 0, 0); }
+    }
+#undef MSIREN_X1_LAUNCH
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 bool use_f16x3(msiren_ctx* h) {
     return h->cfg.precision == MSIREN_PREC_F16X3 && h->f16x3_ready && !h->cfg.residual &&
            msiren::F16Lds<3>::total(h->L) <= 160 * 1024;
@@ -515,7 +645,7 @@ bool use_f16x3(msiren_ctx* h) {
 
 int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     if (B == 0) return 0;
-    if (use_f16x3(h)) {
+    if (use_f16x3(h) || h->x1_ready) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->profile) {
             if (h->prof_used == h->prof_events.size()) {
@@ -529,7 +659,7 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
             h->prof_used++;
             HIPCHK(hipEventRecord(e0, h->sc[h->cur].s));
         }
-        int rc = launch_trunk_f16x3(h, mods_dev, B, out_dev);
+        int rc = h->x1_ready ? launch_trunk_x1(h, mods_dev, B, out_dev) : launch_trunk_f16x3(h, mods_dev, B, out_dev);
         if (rc) return rc;
         if (h->profile) HIPCHK(hipEventRecord(e1, h->sc[h->cur].s));
         return 0;
@@ -697,8 +827,8 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (cfg->inner_patch_size < 1 || cfg->outer_patch_size < cfg->inner_patch_size)
         return fail(MSIREN_E_INVALID, "need outer_patch_size >= inner_patch_size >= 1");
     if (cfg->activation != MSIREN_ACT_SINE && cfg->activation != MSIREN_ACT_MORLET) return fail(MSIREN_E_INVALID, "unknown activation %d", cfg->activation);
-    if (cfg->precision != MSIREN_PREC_F32 && cfg->precision != MSIREN_PREC_F16X3)
-        return fail(MSIREN_E_INVALID, "precision %d is not available in this build (f32 = 0, f16x3 = 2)", cfg->precision);
+    if (cfg->precision < MSIREN_PREC_F32 || cfg->precision > MSIREN_PREC_F16)
+        return fail(MSIREN_E_INVALID, "unknown precision %d", cfg->precision);
     if (cfg->w0 == 0.f || cfg->w0_initial == 0.f) return fail(MSIREN_E_INVALID, "w0 and w0_initial must be non-zero");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -738,7 +868,9 @@ int msiren_destroy(msiren_handle h) {
     for (auto& c : h->sc)
         if (c.s) (void)hipStreamSynchronize(c.s);
     if (h->d_wp16) (void)hipFree(h->d_wp16);
-    float* ptrs[] = {h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
+    for (void* q : {h->d_wpx1, h->d_biasx1, h->d_woutx1})
+        if (q) (void)hipFree(q);
+    float* ptrs[] = {h->d_l0last, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
@@ -775,6 +907,7 @@ int msiren_commit_weights(msiren_handle h) {
     if ((rc = sync_all(h))) return rc;
     if ((rc = pack_trunk(h))) return rc;
     if ((rc = pack_trunk_f16x3(h))) return rc;
+    if ((rc = pack_trunk_x1(h))) return rc;
     if ((rc = pack_fold_weights(h))) return rc;
     rc = pack_modulator(h);
     if (rc < 0) return rc;

@@ -161,7 +161,8 @@ class ModulatedSiren:
         cfg.outer_patch_size, cfg.inner_patch_size = self.outer_patch_size, self.inner_patch_size
         cfg.siren_patch_size = self.siren_patch_size
         cfg.residual = int(self.residual)
-        cfg.precision = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "f16x3": _lib.PREC_F16X3}[self.precision]
+        cfg.precision = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "f16x3": _lib.PREC_F16X3,
+                         "f16": _lib.PREC_F16, "fp16": _lib.PREC_F16}[self.precision]
         cfg.device = int(self._device or 0)
         return cfg
 

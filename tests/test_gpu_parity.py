@@ -302,3 +302,34 @@ def test_residual_variant_vs_own_oracle(H, L, Z, act):
     ref32 = orc.siren_forward(sd, mods, num_layers=L, activation=act, residual=True)
     e = nerr(out.reshape(6, -1), ref)
     assert e <= max(1e-4, 10 * nerr(ref32, ref)), (e, nerr(ref32, ref))
+
+
+@pytest.mark.parametrize("prec,res,act,tol", [("bf16", True, "sine", 6e-2), ("bf16", False, "sine", 6e-2),
+                                               ("f16", True, "sine", 8e-3), ("f16", False, "morlet", 8e-3)])
+def test_config5_16bit_trunk_vs_own_oracle(prec, res, act, tol):
+    """BASELINE config 5: 10 x 512, latent 128, 16-bit operands / fp32 accumulate, register-resident trunk.
+    PARITY UNPINNED against the reference (residual branch not in the container); the tolerance is the
+    operand format's: bf16 has an 8-bit significand (2^-9 per rounding, ~10 roundings deep), fp16 11 bits."""
+    H, L, Z, B = 512, 10, 128, 9
+    sd = syn.make_state_dict(seed=21, dim_hidden=H, num_layers=L, latent_dim=Z, with_encoder=False)
+    sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
+    m = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda", activation=act,
+                       residual=res, precision=prec)
+    m.load_state_dict(sd, strict=False)
+    m.to("cuda")
+    mods = syn.make_mods(8, L, B, H, lo=0.1, hi=0.6)
+    out = m.forward_mods(mods)
+    ref = orc.siren_forward(sd, mods, num_layers=L, activation=act, residual=res, dtype=np.float64)
+    e = nerr(out.reshape(B, -1), ref)
+    assert np.isfinite(out).all() and e <= tol, e
+    assert np.array_equal(out, m.forward_mods(mods))
+    # the fp32 trunk on the same model is the high-precision cross-check of the 16-bit one
+    m32 = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=1.0, w0_initial=30.0,
+                         use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                         outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda", activation=act,
+                         residual=res)
+    m32.load_state_dict(sd, strict=False)
+    m32.to("cuda")
+    assert nerr(m32.forward_mods(mods).reshape(B, -1), ref) < 1e-4
