@@ -187,6 +187,10 @@ MSIREN_API int msiren_abi_version(void);
 /* Diagnostic (H=256, sine only): runs a stamped build of the trunk kernel once and returns, per
  * workgroup, 32 uint64: [0] HW_ID, [1] LDS_ALLOC, [2] XCC_ID, [3] s_memrealtime at start,
  * [4..] s_memtime at each phase boundary.  Never used by the forward entry points. */
+/* Same for the f16x3 trunk: per workgroup and pass (first 8), 8 uint64: s_memtime at pass start, after
+ * layer 0, after hidden layers 1..4, at pass end, and s_memrealtime at pass end.  (H=256, L=5, sine.) */
+MSIREN_API int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev,
+                                     uint64_t* stamps_host);
 MSIREN_API int msiren_trunk_timeline(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev,
                                      uint64_t* stamps_host);
 

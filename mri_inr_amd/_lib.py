@@ -83,6 +83,7 @@ PROTOTYPES = {
     "msiren_device_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_uint64)]),
     "msiren_flops_per_coord": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "msiren_trunk_timeline": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "msiren_f16x3_timeline": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
 }
 
 _lib = None

@@ -575,8 +575,6 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     const int64_t units = B * p.units_per_patch;
     if (units > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     p.total_units = (int)units;
-    p.dbg_flags = 0;
-    if (const char* e = std::getenv("MSIREN_F16_FLAGS")) p.dbg_flags = std::atoi(e);
     const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
     {   // pass queue: workgroup g starts with pass g, further passes come from this counter
         int rc = ensure(h, h->sc[h->cur].queue, 256);
@@ -1214,6 +1212,37 @@ int msiren_trunk_timeline(msiren_handle h, const float* mods_dev, int64_t B, flo
     HIPCHK(hipMemcpyAsync(stamps_host, st.p, (size_t)grid * 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
     HIPCHK(hipFree(st.p));
+    return 0;
+}
+
+int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev, uint64_t* stamps_host) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (!h->f16x3_ready || h->cfg.activation != MSIREN_ACT_SINE) return fail(MSIREN_E_INVALID, "f16x3 timeline: H=256 sine model required");
+    msiren::TrunkF16Params p{};
+    p.grid = h->d_grid; p.l0 = h->d_l0; p.s0t = h->d_s0t; p.wp = (const _Float16*)h->d_wp16; p.bias = h->d_bias16;
+    p.wout = h->d_wout16; p.mods = mods_dev; p.out = out_dev;
+    for (int i = 0; i < 16; ++i) p.winv[i] = h->winv16[i];
+    p.bout = h->bout; p.cg0 = h->cg0; p.cg = h->cg; p.B = (int)B; p.P = h->P; p.L = h->L;
+    p.units_per_patch = (h->P + 31) / 32;
+    p.total_units = (int)(B * p.units_per_patch);
+    const int grid = (int)std::min<int64_t>(h->num_cus, (p.total_units + 3) / 4);
+    DevBuf st, q;
+    if ((rc = ensure(h, st, (size_t)grid * 4 * 48 * sizeof(uint64_t))) || (rc = ensure(h, q, 256))) return rc;
+    hipStream_t s = h->sc[h->cur].s;
+    HIPCHK(hipMemsetAsync(st.p, 0, (size_t)grid * 4 * 48 * sizeof(uint64_t), s));
+    p.pass_counter = (int*)q.p;
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p.pass_counter, grid, 1, s));
+    p.stamps = (unsigned long long*)st.p;
+    const int lds = msiren::F16Lds<4>::total(h->L);
+    auto k = msiren::siren_trunk_f16x3_kernel<0, 4, 1>;
+    HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(stamps_host, st.p, (size_t)grid * 4 * 48 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(st.p));
+    HIPCHK(hipFree(q.p));
     return 0;
 }
 

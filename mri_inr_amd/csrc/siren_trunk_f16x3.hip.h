@@ -46,7 +46,7 @@ struct TrunkF16Params {
     float bout, cg0, cg;
     int B, P, L, units_per_patch, total_units;
     int* pass_counter;        // work queue: next pass id; the host sets it to gridDim.x before every launch
-    int dbg_flags;            // experiment knobs (MSIREN_F16_FLAGS): 1 = skip the weight DMA (timing only, wrong results)
+    unsigned long long* stamps; // diagnostic instantiation only: [grid][8 passes][8] s_memtime + realtime
 };
 
 constexpr int F16_CHUNK_BYTES = 32768;
@@ -60,7 +60,8 @@ struct F16Lds {  // byte offsets into dynamic LDS
     static constexpr int bias = zero + 1024;        // (L-1) x 256 floats
     static __host__ __device__ constexpr int mods(int L) { return bias + (L - 1) * 1024; }  // 4 waves x L x 256 floats
     static __host__ __device__ constexpr int queue(int L) { return mods(L) + 4 * L * 1024; }  // 2 ints: next pass id
-    static __host__ __device__ constexpr int total(int L) { return queue(L) + 16; }
+    static __host__ __device__ constexpr int winv(int L) { return queue(L) + 16; }  // per-layer inverse weight scales
+    static __host__ __device__ constexpr int total(int L) { return winv(L) + 64; }
 };
 
 __device__ __forceinline__ h8 pack_h8(fp16x2 a, fp16x2 b, fp16x2 c, fp16x2 d) {
@@ -104,7 +105,7 @@ __device__ __forceinline__ void split4(const f32x4 v, fp16x2& h01, fp16x2& h23, 
     l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
 }
 
-template <int ACT, int R>
+template <int ACT, int R, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Params p) {
     using LY = F16Lds<R>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -144,6 +145,11 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     // launches in flight on different streams a workgroup may start late on a CU the previous launch has
     // just released, and then simply takes fewer passes -- every CU stays busy until the queue is empty.
     volatile int* qslot = reinterpret_cast<volatile int*>(smem + LY::queue(L));
+    // The per-layer inverse scales are indexed at run time.  Read straight from the kernel-argument segment
+    // (host-visible memory) every such s_load that misses the scalar cache costs microseconds -- measured:
+    // ~13k cycles at every layer boundary.  They are copied to LDS once instead.
+    float* winvT = reinterpret_cast<float*>(smem + LY::winv(L));
+    if (tid < 16) winvT[tid] = p.winv[tid];
     int cur_pass = (int)blockIdx.x;
     // each wave moves its 8 KB slice of a chunk: 8 x 1 KB global_load_lds_dwordx4, one base address
     // pair (biased by +4 KB so that the eight 1 KB steps fit the 13-bit signed immediate, which the
@@ -308,6 +314,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 7);                                         \
         __builtin_amdgcn_sched_barrier(0);                                                    \
         if ((T) > 0) epi_store2(1, OUTh[(2 * (T) + 15) & 15], OUTl[(2 * (T) + 15) & 15]);     \
+        if constexpr (DBG) { stamp(8 + dbg_tile); ++dbg_tile; }                               \
     } while (0)
 
     // one hidden layer: IN -> OUT.  The previous layer's last tile still sits in acc[1]; its epilogue
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         const unsigned char* ml_ = modB + l_ * 1024;                                          \
         const unsigned char* blp_ = l_ > 1 ? biasB + (l_ - 2) * 1024 : zeroB;                 \
         const unsigned char* mlp_ = modB + (l_ - 1) * 1024;                                   \
-        const float wi_ = p.winv[l_ - 1], wip_ = l_ > 1 ? p.winv[l_ - 2] : 1.0f;              \
+        const float wi_ = winvT[l_ - 1], wip_ = l_ > 1 ? winvT[l_ - 2] : 1.0f;              \
         const float cgp_ = l_ > 1 ? p.cg : p.cg0;                                             \
         MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 0);                                             \
         MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 1);                                             \
@@ -345,6 +352,15 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     }
 
     for (int pass = 0; cur_pass * 4 < p.total_units; ++pass) {
+        auto stamp = [&](int i) {
+            if constexpr (DBG) {
+                const unsigned long long t = i == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
+                if (tid == 0 && pass < 4) p.stamps[((size_t)blockIdx.x * 4 + pass) * 48 + i] = t;
+            }
+        };
+        stamp(0);
+        int dbg_tile = 0;
+        (void)dbg_tile;
         int unit = cur_pass * 4 + wave;
         const bool active = unit < p.total_units;
         unit = active ? unit : p.total_units - 1;
@@ -407,20 +423,25 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         tbl_load(0, zeroB, modB, zeroB, 7, 0);  // part 0 of the layer-0 "pending" tile
 
         part = 0.f;
+        stamp(1);
         for (int l = 1; l < L; l += 2) {
             MSIREN_F16_LAYER(Xh, Xl, Yh, Yl, l);
+            stamp(l == 1 ? 2 : 4);
             if (l + 1 < L) MSIREN_F16_LAYER(Yh, Yl, Xh, Xl, l + 1);
+            stamp(l == 1 ? 3 : 5);
         }
         // the final hidden layer's last tile is still pending: only its contribution to `part` matters
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g > 0) tbl_load(g & 1, biasB + (L - 2) * 1024, modB + (L - 1) * 1024, woutB, 7, g);
-            epi_half(acc[1], p.winv[L - 2], p.cg, g & 1, g, 0);
-            epi_half(acc[1], p.winv[L - 2], p.cg, g & 1, g, 1);
+            epi_half(acc[1], winvT[L - 2], p.cg, g & 1, g, 0);
+            epi_half(acc[1], winvT[L - 2], p.cg, g & 1, g, 1);
         }
         part += __shfl_xor(part, 32);
         if (pvalid && half == 0) p.out[(size_t)b * p.P + pc] = sin_rev(part + p.bout);
         cur_pass = __builtin_amdgcn_readfirstlane(qslot[(pass + 1) & 1]);
+        stamp(6);
+        stamp(7);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may be in flight when the LDS is released
 #undef MSIREN_F16_LAYER

@@ -54,7 +54,8 @@ struct X1Lds {
     static constexpr int bias = zero + 1024;       // (L-1) x 512 x fp16
     static __host__ __device__ constexpr int mods(int L) { return bias + (L - 1) * 1024; }  // 4 waves x L x 512 x fp16
     static __host__ __device__ constexpr int queue(int L) { return mods(L) + 4 * L * 1024; }
-    static __host__ __device__ constexpr int total(int L) { return queue(L) + 16; }
+    static __host__ __device__ constexpr int winv(int L) { return queue(L) + 16; }  // per-layer inverse weight scales
+    static __host__ __device__ constexpr int total(int L) { return winv(L) + 256; }
 };
 
 __device__ __forceinline__ u32x4 x1_to_acc_file(u32x4 v) {
@@ -129,6 +130,11 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
     }
 
     volatile int* qslot = reinterpret_cast<volatile int*>(smem + LY::queue(L));
+    // The per-layer inverse scales are indexed at run time.  Read straight from the kernel-argument segment
+    // (host-visible memory) every such s_load that misses the scalar cache costs microseconds -- measured:
+    // ~13k cycles at every layer boundary.  They are copied to LDS once instead.
+    float* winvT = reinterpret_cast<float*>(smem + LY::winv(L));
+    if (tid < 64) winvT[tid] = p.winv[tid];
     int cur_pass = (int)blockIdx.x;
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wp) + wave * 8192 + lane * 16 + 4096;
     int dma_id = 0, dma_buf = 0, rd_buf = 0;
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
         const unsigned char* ml_ = modB + l_ * 1024;                                          \
         const unsigned char* blp_ = l_ > 1 ? biasB + (l_ - 2) * 1024 : zeroB;                 \
         const unsigned char* mlp_ = modB + (l_ - 1) * 1024;                                   \
-        const float wi_ = p.winv[l_ - 1], wip_ = l_ > 1 ? p.winv[l_ - 2] : 1.0f;              \
+        const float wi_ = winvT[l_ - 1], wip_ = l_ > 1 ? winvT[l_ - 2] : 1.0f;              \
         const float cgp_ = l_ > 1 ? p.cg : p.cg0;                                             \
         const float rfp_ = l_ > 1 ? 1.0f : 0.0f; /* layer 0 has no skip connection */         \
         MSIREN_X1_TILE(IN, OUT, 0);                                                           \
@@ -383,8 +389,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
                 u32x4 old;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) old[w] = odd ? X[30 + (g >> 1)][w] : Y[30 + (g >> 1)][w];
-                epi_half(acc[1], p.winv[L - 2], p.cg, g & 1, g, 0, old, 1.0f);
-                epi_half(acc[1], p.winv[L - 2], p.cg, g & 1, g, 1, old, 1.0f);
+                epi_half(acc[1], winvT[L - 2], p.cg, g & 1, g, 0, old, 1.0f);
+                epi_half(acc[1], winvT[L - 2], p.cg, g & 1, g, 1, old, 1.0f);
             }
         }
         part += __shfl_xor(part, 32);

@@ -85,7 +85,7 @@ class ModulatedSiren:
 
     def __init__(self, dim_in, dim_hidden, dim_out, num_layers, latent_dim, w0, w0_initial, use_bias,
                  dropout, modulate, encoder_type, encoder_path, outer_patch_size, inner_patch_size,
-                 siren_patch_size, device, activation, *, residual=False, precision="fp32"):
+                 siren_patch_size, device, activation, *, residual=False, precision="auto"):
         # attribute names as in the reference (:389-398)
         self.dim_in = int(dim_in)
         self.dim_hidden = int(dim_hidden)
@@ -161,7 +161,9 @@ class ModulatedSiren:
         cfg.outer_patch_size, cfg.inner_patch_size = self.outer_patch_size, self.inner_patch_size
         cfg.siren_patch_size = self.siren_patch_size
         cfg.residual = int(self.residual)
-        cfg.precision = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "f16x3": _lib.PREC_F16X3,
+        # "auto": the split-fp16 trunk (fp32-equivalent accuracy, ~3x faster) wherever the library supports the
+        # shape (H = 256, 2 <= L <= 12, no residual); the library itself falls back to the fp32 trunk otherwise
+        cfg.precision = {"auto": _lib.PREC_F16X3, "fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "f16x3": _lib.PREC_F16X3,
                          "f16": _lib.PREC_F16, "fp16": _lib.PREC_F16}[self.precision]
         cfg.device = int(self._device or 0)
         return cfg

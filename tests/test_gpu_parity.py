@@ -333,3 +333,24 @@ def test_config5_16bit_trunk_vs_own_oracle(prec, res, act, tol):
     m32.load_state_dict(sd, strict=False)
     m32.to("cuda")
     assert nerr(m32.forward_mods(mods).reshape(B, -1), ref) < 1e-4
+
+
+def test_default_precision_is_the_fast_exact_trunk():
+    """precision="auto" (the default) selects the f16x3 trunk where supported and must agree with the
+    explicit choices bit for bit; unsupported shapes silently use the fp32 trunk."""
+    sd = syn.make_state_dict(seed=7)
+    mods = syn.make_mods(3, 5, 12, 256)
+    a = make_model(sd).forward_mods(mods)
+    assert np.array_equal(a, make_model(sd, precision="f16x3").forward_mods(mods))
+    sd2 = syn.make_state_dict(seed=7, dim_hidden=128, num_layers=3, with_encoder=False)
+    sd2 = {k: v for k, v in sd2.items() if not k.startswith("modulator")}
+    outs = []
+    for prec in ("auto", "fp32"):
+        m = ModulatedSiren(dim_in=2, dim_hidden=128, dim_out=1, num_layers=3, latent_dim=256, w0=1.0, w0_initial=30.0,
+                           use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                           outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda",
+                           activation="sine", precision=prec)
+        m.load_state_dict(sd2, strict=False)
+        m.to("cuda")
+        outs.append(m.forward_mods(syn.make_mods(3, 3, 4, 128)))
+    assert np.array_equal(outs[0], outs[1])
