@@ -60,6 +60,7 @@ struct msiren_ctx {
     struct StreamCtx {
         hipStream_t s = nullptr;
         DevBuf mods, modpad, latent, patches, keep, rec, queue;
+        unsigned queue_base = 0;  // value of the pass counter when the next launch starts
     } sc[2];
     int cur = 0, nstreams = 1;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -539,6 +540,23 @@ msiren::TrunkParams make_trunk_params(msiren_ctx* h, const float* mods, int stri
     return p;
 }
 
+// Pass queue of the persistent trunks.  Workgroup g starts with pass g; every executed pass performs exactly
+// one atomicAdd on the counter, so a launch of n passes advances it by n: the counter is never reset, the
+// host hands each launch the value it will find (no memset node per call).
+int queue_for_launch(msiren_ctx* h, int64_t npasses, int** counter, unsigned* base) {
+    auto& c = h->sc[h->cur];
+    if (!c.queue.p) {
+        int rc = ensure(h, c.queue, 256);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(c.queue.p, 0, 256, c.s));
+        c.queue_base = 0;
+    }
+    *counter = (int*)c.queue.p;
+    *base = c.queue_base;
+    c.queue_base += (unsigned)npasses;
+    return 0;
+}
+
 template <int R>
 int launch_trunk_f16x3_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int grid) {
     const int lds = msiren::F16Lds<R>::total(h->L);
@@ -577,10 +595,8 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     p.total_units = (int)units;
     const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
     {   // pass queue: workgroup g starts with pass g, further passes come from this counter
-        int rc = ensure(h, h->sc[h->cur].queue, 256);
+        int rc = queue_for_launch(h, (units + 3) / 4, &p.pass_counter, &p.pass_base);
         if (rc) return rc;
-        p.pass_counter = (int*)h->sc[h->cur].queue.p;
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p.pass_counter, grid, 1, h->sc[h->cur].s));
     }
     // R = 3 leaves ~35 KB of LDS per CU free, enough for an encoder / modulator workgroup of the NEXT
     // call (other stream) to run beside the persistent trunk workgroup; R = 4 fills the CU.
@@ -612,10 +628,8 @@ int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_
     if (units > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     p.total_units = (int)units;
     const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
-    int rc = ensure(h, h->sc[h->cur].queue, 256);
+    int rc = queue_for_launch(h, (units + 3) / 4, &p.pass_counter, &p.pass_base);
     if (rc) return rc;
-    p.pass_counter = (int*)h->sc[h->cur].queue.p;
-    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p.pass_counter, grid, 1, h->sc[h->cur].s));
     const int lds = msiren::X1Lds<3>::total(h->L);
     const bool bf = h->cfg.precision == MSIREN_PREC_BF16, mor = h->cfg.activation == MSIREN_ACT_MORLET, res = h->cfg.residual != 0;
 #define MSIREN_X1_LAUNCH(BF, A, RS)                                                                  \
@@ -1232,7 +1246,8 @@ int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, flo
     hipStream_t s = h->sc[h->cur].s;
     HIPCHK(hipMemsetAsync(st.p, 0, (size_t)grid * 4 * 48 * sizeof(uint64_t), s));
     p.pass_counter = (int*)q.p;
-    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)p.pass_counter, grid, 1, s));
+    HIPCHK(hipMemsetAsync(p.pass_counter, 0, 4, s));
+    p.pass_base = 0;
     p.stamps = (unsigned long long*)st.p;
     const int lds = msiren::F16Lds<4>::total(h->L);
     auto k = msiren::siren_trunk_f16x3_kernel<0, 4, 1>;

@@ -45,7 +45,8 @@ struct TrunkF16Params {
     float winv[16];           // per hidden layer: exact inverse of the power-of-two weight scale
     float bout, cg0, cg;
     int B, P, L, units_per_patch, total_units;
-    int* pass_counter;        // work queue: next pass id; the host sets it to gridDim.x before every launch
+    int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
+    unsigned pass_base;        // work queue: next pass id; the host sets it to gridDim.x before every launch
     unsigned long long* stamps; // diagnostic instantiation only: [grid][8 passes][8] s_memtime + realtime
 };
 
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
 
         // the next pass id is fetched a whole pass ahead, together with the loads below (one wait)
         int nxt = 0;
-        if (tid == 0) nxt = atomicAdd(p.pass_counter, 1);
+        if (tid == 0) nxt = (int)((unsigned)atomicAdd(p.pass_counter, 1) - p.pass_base) + (int)gridDim.x;
         // this wave's modulation table: (L, 256) floats of patch b
         for (int l = 0; l < L; ++l) {
             const f32x4 m = *reinterpret_cast<const f32x4*>(p.mods + ((size_t)l * p.B + b) * 256 + lane * 4);

@@ -40,7 +40,8 @@ struct TrunkX1Params {
     float winv[64];           // per hidden layer: exact inverse of the power-of-two weight scale
     float bout, cg0, cg;
     int B, P, L, units_per_patch, total_units;
-    int* pass_counter;
+    int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
+    unsigned pass_base;
 };
 
 constexpr int X1_CHUNK_BYTES = 32768;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
         pc = pc < p.P ? pc : p.P - 1;
 
         int nxt = 0;
-        if (tid == 0) nxt = atomicAdd(p.pass_counter, 1);
+        if (tid == 0) nxt = (int)((unsigned)atomicAdd(p.pass_counter, 1) - p.pass_base) + (int)gridDim.x;
         // this wave's modulation table: (L, 512) of patch b, narrowed to fp16
         for (int l = 0; l < L; ++l)
 #pragma unroll
