@@ -354,3 +354,64 @@ def test_default_precision_is_the_fast_exact_trunk():
         m.to("cuda")
         outs.append(m.forward_mods(syn.make_mods(3, 3, 4, 128)))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_tiling_kernels_vs_reference_fixtures():
+    """image_to_patches / weighted fold on the device against outputs of the reference's tiling.py."""
+    import ctypes as C
+
+    from mri_inr_amd import _lib
+
+    g = load_golden("tiling.npz")
+    sd = syn.make_state_dict(seed=7)
+    m = make_model(sd)
+    for name, (hh, ww) in (("320x320", (320, 320)), ("70x50", (70, 50))):
+        img = syn.make_slice(3, hh, ww, brain_mask=(name == "320x320"))
+        nv, nh = C.c_int32(), C.c_int32()
+        _lib.check(m._lib.msiren_recon_shape(m._h, hh, ww, C.byref(nv), C.byref(nh)))
+        assert (nv.value, nh.value) == tuple(g[f"info_{name}"])
+        n = nv.value * nh.value
+        d_img = m.device_array((1, hh, ww)).copy_from(img[None])
+        d_p = m.device_array((n, 32, 32))
+        _lib.check(m._lib.msiren_image_to_patches_dev(m._h, d_img.ptr, 1, hh, ww, d_p.ptr))
+        m.sync()
+        assert np.array_equal(d_p.numpy(), g[f"patches_{name}"])  # byte moving: bit-exact
+        rec = np.random.default_rng(5).random((n, 24, 24), dtype=np.float32)
+        d_r = m.device_array(rec.shape).copy_from(rec)
+        d_o = m.device_array((1, nv.value * 16, nh.value * 16))
+        _lib.check(m._lib.msiren_weighted_fold_dev(m._h, d_r.ptr, 1, nv.value, nh.value, d_o.ptr))
+        m.sync()
+        assert nerr(d_o.numpy()[0], g[f"wfold_{name}"][0]) < 1e-6
+    # reflect padding needs pad < dim, as F.pad does
+    d_small = m.device_array((1, 6, 6))
+    d_ps = m.device_array((1, 32, 32))
+    with pytest.raises(ValueError):
+        _lib.check(m._lib.msiren_image_to_patches_dev(m._h, d_small.ptr, 1, 6, 6, d_ps.ptr))
+
+
+def test_black_patch_semantics_match_reference():
+    """Zero tiles are skipped by the reference and re-inserted as zeros WITH their fold weight
+    (tiling.py:287-301, :117-118): neighbours are pulled down.  Known answer from SURVEY.md §8(f)."""
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = make_model(sd)
+    img = syn.make_slice(0, 160, 128, brain_mask=True)
+    rec = m.reconstruct(img)
+    ref = orc.reconstruct_slice(sd, img, num_layers=5, dtype=np.float64)
+    check(rec, ref.astype(np.float32), tol=1e-4)
+    assert np.all(rec[:8, :8] == 0.0)  # the corner patch is black: exactly zero there
+
+
+def test_deep_model_falls_back_to_fp32_trunk():
+    L = 14  # beyond the f16x3 kernel's LDS budget: the library must use the fp32 trunk silently
+    sd = syn.make_state_dict(seed=2, num_layers=L, with_encoder=False)
+    sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
+    m = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=L, latent_dim=256, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda", activation="sine")
+    m.load_state_dict(sd, strict=False)
+    m.to("cuda")
+    mods = syn.make_mods(5, L, 3, 256, lo=0.3, hi=0.9)
+    ref = orc.siren_forward(sd, mods, num_layers=L, dtype=np.float64)
+    e32 = nerr(orc.siren_forward(sd, mods, num_layers=L), ref)
+    e = nerr(m.forward_mods(mods).reshape(3, -1), ref)
+    assert e <= max(1e-4, 10 * e32), (e, e32)
