@@ -14,7 +14,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsiren.so")
+LIB_PATH = os.environ.get("MSIREN_LIB") or os.path.join(_HERE, "libmsiren.so")  # MSIREN_LIB: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msiren.h")
 
 ABI_VERSION = 1

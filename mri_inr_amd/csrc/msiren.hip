@@ -563,7 +563,12 @@ int launch_trunk_f16x3_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int gri
     auto k0 = msiren::siren_trunk_f16x3_kernel<0, R>;
     auto k1 = msiren::siren_trunk_f16x3_kernel<1, R>;
     const void* kp = h->cfg.activation == MSIREN_ACT_MORLET ? (const void*)k1 : (const void*)k0;
-    HIPCHK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    static int lds_set[2] = {0, 0};  // per template instantiation (R) and activation: raise the limit once
+    int& done = lds_set[h->cfg.activation == MSIREN_ACT_MORLET ? 1 : 0];
+    if (done < lds) {
+        HIPCHK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        done = lds;
+    }
     if (h->cfg.activation == MSIREN_ACT_MORLET)
         hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
     else
@@ -593,7 +598,8 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     const int64_t units = B * p.units_per_patch;
     if (units > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     p.total_units = (int)units;
-    const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
+    int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
+    if (const char* e = std::getenv("MSIREN_GRID")) grid = std::max(1, std::min(grid, std::atoi(e)));  // experiment knob
     {   // pass queue: workgroup g starts with pass g, further passes come from this counter
         int rc = queue_for_launch(h, (units + 3) / 4, &p.pass_counter, &p.pass_base);
         if (rc) return rc;

@@ -157,27 +157,30 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     // instruction applies to the global AND the LDS address)
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wp) + wave * 8192 + lane * 16 + 4096;
     int dma_id = 0, dma_buf = 0, rd_buf = 0;
-    auto dma_next = [&]() {
-        {   // unconditional: past the last chunk the ring is refilled with (unused) wrapped-around data;
-            // the kernel drains vmcnt before it exits
-
-            const unsigned char* src = wsrc + (size_t)dma_id * F16_CHUNK_BYTES;
-            unsigned char* dst = smem + LY::ring + dma_buf * F16_CHUNK_BYTES + wave * 8192 + 4096;
-#define MSIREN_DMA(I)                                                                                     \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,                  \
-                                     (__attribute__((address_space(3))) void*)dst, 16, (I) * 1024 - 4096, 0)
-            MSIREN_DMA(0);
-            MSIREN_DMA(1);
-            MSIREN_DMA(2);
-            MSIREN_DMA(3);
-            MSIREN_DMA(4);
-            MSIREN_DMA(5);
-            MSIREN_DMA(6);
-            MSIREN_DMA(7);
-#undef MSIREN_DMA
-        }
+    // One chunk = 8 pieces of 1 KB per wave.  dma_next() issues them as a block (prologue only); inside a
+    // tile they are spread over the four scheduling groups after the ring barrier (MSIREN_DMA_PIECE), so
+    // the MFMA stream is not interrupted by a block of eight address/M0/DMA issues.
+    const unsigned char* dsrc_ = wsrc;
+    unsigned char* ddst_ = smem + LY::ring + wave * 8192 + 4096;
+    auto dma_begin = [&]() {
+        dsrc_ = wsrc + (size_t)dma_id * F16_CHUNK_BYTES;
+        ddst_ = smem + LY::ring + dma_buf * F16_CHUNK_BYTES + wave * 8192 + 4096;
         dma_id = dma_id + 1 == nchunks ? 0 : dma_id + 1;
         dma_buf = dma_buf + 1 == R ? 0 : dma_buf + 1;
+    };
+#define MSIREN_DMA_PIECE(I)                                                                               \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)dsrc_,                \
+                                     (__attribute__((address_space(3))) void*)ddst_, 16, (I) * 1024 - 4096, 0)
+    auto dma_next = [&]() {
+        dma_begin();
+        MSIREN_DMA_PIECE(0);
+        MSIREN_DMA_PIECE(1);
+        MSIREN_DMA_PIECE(2);
+        MSIREN_DMA_PIECE(3);
+        MSIREN_DMA_PIECE(4);
+        MSIREN_DMA_PIECE(5);
+        MSIREN_DMA_PIECE(6);
+        MSIREN_DMA_PIECE(7);
     };
     if (cur_pass * 4 >= p.total_units) return;
 #pragma unroll
@@ -246,33 +249,19 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     // Epilogue schedule.  T > 0: tile T-1, half (Q&1) of part Q>>1 per group; T == 0: the previous layer's
     // tile 7 ("pending"), whose result feeds k-steps 14, 15 of THIS tile, so: parts 0..3 in groups 0..3,
     // stores in groups 4 and 5.
-#define MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, Q)                                          \
+// Ablation builds (timing only, results wrong; never shipped): -DMSIREN_ABL=bitmask
+//   1 = no epilogue work in the groups, 2 = no ring barrier / vmcnt wait, 4 = no weight-fragment LDS reads
+#ifndef MSIREN_ABL
+#define MSIREN_ABL 0
+#endif
+#ifndef MSIREN_SGB_VARIANT
+#define MSIREN_SGB_VARIANT 1
+#endif
+#if MSIREN_SGB_VARIANT == 0
+#define MSIREN_F16_SGB() do {} while (0)
+#elif MSIREN_SGB_VARIANT == 1
+#define MSIREN_F16_SGB()                                                                      \
     do {                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-        {                                                                                     \
-            const h8* src_ = (Q) < 7 ? ring_ + (4 * (((Q) + 1) & 7)) * 64 : ringn_;           \
-            wf_[((Q) + 1) & 1][0] = src_[0 * 64];                                             \
-            wf_[((Q) + 1) & 1][1] = src_[1 * 64];                                             \
-            wf_[((Q) + 1) & 1][2] = src_[2 * 64];                                             \
-            wf_[((Q) + 1) & 1][3] = src_[3 * 64];                                             \
-        }                                                                                     \
-        if ((T) == 0) {                                                                       \
-            if ((Q) < 3) tbl_load(((Q) + 1) & 1, blp_, mlp_, zeroB, 7, ((Q) + 1) & 3);        \
-            if ((Q) < 4) {                                                                    \
-                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 0);                            \
-                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 1);                            \
-            }                                                                                 \
-            if ((Q) == 4) epi_store2(0, INh[14], INl[14]);                                    \
-            if ((Q) == 5) epi_store2(1, INh[15], INl[15]);                                    \
-        } else {                                                                              \
-            if (((Q) & 1) == 1 && (Q) < 7) tbl_load((((Q) >> 1) + 1) & 1, bl_, ml_, wo_, ((T) + 7) & 7, (((Q) >> 1) + 1) & 3); \
-            epi_half(acc[((T) + 1) & 1], wi_, p.cg, ((Q) >> 1) & 1, (Q) >> 1, (Q) & 1);       \
-            if ((Q) == 5) epi_store2(0, OUTh[(2 * (T) + 14) & 15], OUTl[(2 * (T) + 14) & 15]); \
-        }                                                                                     \
-        if ((Q) == 7) tbl_load(0, bl_, ml_, wo_, (T), 0); /* part 0 of THIS tile's epilogue (runs next tile) */ \
-        MSIREN_F16_KSTEP(INh, INl, T, Q, 0);                                                  \
-        MSIREN_F16_KSTEP(INh, INl, T, Q, 1);                                                  \
-        /* requested issue order inside the region: the weight-fragment reads first, VALU spread */ \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                    \
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                    \
@@ -291,6 +280,63 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
         __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                    \
     } while (0)
+#else  /* 2: three VALU after every MFMA, the DS reads up front */
+#define MSIREN_F16_SGB()                                                                      \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                    \
+    } while (0)
+#endif
+
+#define MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, Q)                                          \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if ((Q) >= 4) { /* two of the eight DMA pieces of chunk c+R-1 per group */            \
+            MSIREN_DMA_PIECE(2 * ((Q) & 3));                                                  \
+            MSIREN_DMA_PIECE(2 * ((Q) & 3) + 1);                                              \
+        }                                                                                     \
+        if (MSIREN_ABL & 4) { /* fragments stay what they are, opaquely */                   \
+            asm volatile("" : "+v"(wf_[((Q) + 1) & 1][0]), "+v"(wf_[((Q) + 1) & 1][1]), "+v"(wf_[((Q) + 1) & 1][2]), "+v"(wf_[((Q) + 1) & 1][3])); \
+        } else {                                                                              \
+            const h8* src_ = (Q) < 7 ? ring_ + (4 * (((Q) + 1) & 7)) * 64 : ringn_;           \
+            wf_[((Q) + 1) & 1][0] = src_[0 * 64];                                             \
+            wf_[((Q) + 1) & 1][1] = src_[1 * 64];                                             \
+            wf_[((Q) + 1) & 1][2] = src_[2 * 64];                                             \
+            wf_[((Q) + 1) & 1][3] = src_[3 * 64];                                             \
+        }                                                                                     \
+        if (MSIREN_ABL & 1) { /* keep the accumulators alive so the MFMAs are not dead code */  \
+            if ((Q) == 0) asm volatile("" ::"v"(acc[((T) + 1) & 1]));                         \
+        } else if ((T) == 0) {                                                                \
+            if ((Q) < 3) tbl_load(((Q) + 1) & 1, blp_, mlp_, zeroB, 7, ((Q) + 1) & 3);        \
+            if ((Q) < 4) {                                                                    \
+                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 0);                            \
+                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 1);                            \
+            }                                                                                 \
+            if ((Q) == 4) epi_store2(0, INh[14], INl[14]);                                    \
+            if ((Q) == 5) epi_store2(1, INh[15], INl[15]);                                    \
+        } else {                                                                              \
+            if (((Q) & 1) == 1 && (Q) < 7) tbl_load((((Q) >> 1) + 1) & 1, bl_, ml_, wo_, ((T) + 7) & 7, (((Q) >> 1) + 1) & 3); \
+            epi_half(acc[((T) + 1) & 1], wi_, p.cg, ((Q) >> 1) & 1, (Q) >> 1, (Q) & 1);       \
+            if ((Q) == 5) epi_store2(0, OUTh[(2 * (T) + 14) & 15], OUTl[(2 * (T) + 14) & 15]); \
+        }                                                                                     \
+        if ((Q) == 7 && !(MSIREN_ABL & 1)) tbl_load(0, bl_, ml_, wo_, (T), 0); /* part 0 of THIS tile's epilogue (runs next tile) */ \
+        MSIREN_F16_KSTEP(INh, INl, T, Q, 0);                                                  \
+        MSIREN_F16_KSTEP(INh, INl, T, Q, 1);                                                  \
+        /* requested issue order inside the region: the weight-fragment reads first, VALU spread */ \
+        MSIREN_F16_SGB();                                                                     \
+    } while (0)
 
     // One tile = one 32 KB weight chunk.  The ring is synchronised in the MIDDLE of the tile: by then
     // every wave has finished the previous tile (so its buffer may be refilled: DMA of chunk c+R-1) and,
@@ -306,15 +352,17 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 2);                                         \
         MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 3);                                         \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 8) : "memory");                    \
-        __builtin_amdgcn_s_barrier();                                                         \
-        dma_next();                                                                           \
+        if (!(MSIREN_ABL & 2)) {                                                              \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 8) : "memory");                \
+            __builtin_amdgcn_s_barrier();                                                     \
+        }                                                                                     \
+        dma_begin();                                                                          \
         MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 4);                                         \
         MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 5);                                         \
         MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 6);                                         \
         MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 7);                                         \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        if ((T) > 0) epi_store2(1, OUTh[(2 * (T) + 15) & 15], OUTl[(2 * (T) + 15) & 15]);     \
+        if ((T) > 0 && !(MSIREN_ABL & 1)) epi_store2(1, OUTh[(2 * (T) + 15) & 15], OUTl[(2 * (T) + 15) & 15]); \
         if constexpr (DBG) { stamp(8 + dbg_tile); ++dbg_tile; }                               \
     } while (0)
 
@@ -449,6 +497,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
 #undef MSIREN_F16_TILE
 #undef MSIREN_F16_GROUP
 #undef MSIREN_F16_KSTEP
+#undef MSIREN_DMA_PIECE
 }
 
 }  // namespace msiren
