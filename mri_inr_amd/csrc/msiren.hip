@@ -563,8 +563,8 @@ int launch_trunk_f16x3_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int gri
     auto k0 = msiren::siren_trunk_f16x3_kernel<0, R>;
     auto k1 = msiren::siren_trunk_f16x3_kernel<1, R>;
     const void* kp = h->cfg.activation == MSIREN_ACT_MORLET ? (const void*)k1 : (const void*)k0;
-    static int lds_set[2] = {0, 0};  // per template instantiation (R) and activation: raise the limit once
-    int& done = lds_set[h->cfg.activation == MSIREN_ACT_MORLET ? 1 : 0];
+    static int lds_set[64][2] = {};  // per device, template instantiation (R) and activation: raise the limit once
+    int& done = lds_set[h->cfg.device & 63][h->cfg.activation == MSIREN_ACT_MORLET ? 1 : 0];
     if (done < lds) {
         HIPCHK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         done = lds;
