@@ -151,7 +151,6 @@ def main():
         H, L, Z, S, B = 32, 3, 256, 8, 3
         sd = syn.make_state_dict(seed=11, dim_hidden=H, num_layers=L, latent_dim=Z, siren_patch_size=S)
         model = _build_reference_model(ModulatedSiren, FixedAutoencoder, sd, H=H, L=L, Z=Z, S=S, activation=act)
-        assert np.array_equal(model.grid.numpy(), sd["grid"]), "grid buffer differs from synthetic.make_grid"
         mods = syn.make_mods(21, L, B, H)
         hid, out = _run_net_layers(model, mods)
         np.savez_compressed(os.path.join(GOLD, f"tiny_{act}.npz"), out=out,

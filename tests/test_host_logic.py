@@ -1,0 +1,104 @@
+"""CPU tests of host-side pieces that need no GPU: synthetic inputs, metrics, weight files."""
+import numpy as np
+import pytest
+
+from mri_inr_amd import metrics, synthetic as syn, weights
+
+
+def test_grid_matches_torch_linspace_meshgrid():
+    """The `grid` buffer of the reference: stack(meshgrid(linspace(-1,1,S), linspace(-1,1,S), 'ij'))
+    (src/networks/modulated_siren.py:427-433).  torch's CPU linspace is vectorised (base + step*lane per SIMD
+    chunk), so its last bit depends on the host's vector width; real checkpoints carry the buffer in their
+    state_dict, which is what the library uses.  The synthetic grid agrees to one ulp."""
+    import torch
+
+    for S in (2, 3, 8, 24, 25, 64):
+        lin = torch.linspace(-1, 1, steps=S)
+        ref = torch.stack(torch.meshgrid(lin, lin, indexing="ij"), dim=-1).reshape(S * S, 2).numpy()
+        assert np.abs(syn.make_grid(S) - ref).max() <= 1.2e-7, S
+        assert syn.make_grid(S)[0].tolist() == [-1.0, -1.0] and syn.make_grid(S)[-1].tolist() == [1.0, 1.0]
+
+
+def test_state_dict_keys_and_shapes_match_reference_layout():
+    sd = syn.make_state_dict(seed=1)
+    want = {
+        "grid": (576, 2), "net.layers.0.weight": (256, 2), "net.layers.4.weight": (256, 256), "net.layers.4.bias": (256,),
+        "net.last_layer.weight": (1, 256), "net.last_layer.bias": (1,), "modulator.layers.0.0.weight": (256, 256),
+        "modulator.layers.3.0.weight": (256, 512), "encoder.encoder.encoder.0.weight": (16, 1, 3, 3),
+        "encoder.encoder.encoder.4.weight": (64, 32, 8, 8), "encoder.encoder.encoder.7.weight": (256, 64),
+    }
+    for k, shp in want.items():
+        assert sd[k].shape == shp and sd[k].dtype == np.float32, k
+    assert len(sd) == 31
+    # Siren.init_ ranges (modulated_siren.py:138-142)
+    assert np.abs(sd["net.layers.0.weight"]).max() <= 0.5
+    assert np.abs(sd["net.layers.2.weight"]).max() <= np.sqrt(6 / 256)
+    # same seed -> same weights; the trained-like preset only shifts modulator biases / encoder fc
+    sd2 = syn.make_state_dict(seed=1, trained_like=True)
+    assert np.array_equal(sd["net.layers.3.weight"], sd2["net.layers.3.weight"])
+    assert not np.array_equal(sd["modulator.layers.0.0.bias"], sd2["modulator.layers.0.0.bias"])
+
+
+def test_slices_are_seeded_and_masked():
+    a, b = syn.make_slice(3), syn.make_slice(3)
+    assert np.array_equal(a, b) and a.shape == (320, 320) and a.dtype == np.float32
+    m = syn.make_slice(3, brain_mask=True)
+    assert m[0, 0] == 0 and m[160, 160] == a[160, 160]
+
+
+def test_metrics_closed_forms():
+    rng = np.random.default_rng(0)
+    a = rng.random((64, 48))
+    b = a + 0.1 * rng.standard_normal(a.shape)
+    dr = max(a.max(), b.max()) - min(a.min(), b.min())
+    assert metrics.calculate_data_range(a, b) == pytest.approx(dr)
+    assert metrics.calculate_psnr(a, b) == pytest.approx(10 * np.log10(dr ** 2 / np.mean((a - b) ** 2)))
+    assert metrics.calculate_nrmse(a, b) == pytest.approx(np.linalg.norm(a - b) / np.linalg.norm(a))
+    assert metrics.calculate_ssim(a, a) == pytest.approx(1.0)
+    assert 0 < metrics.calculate_ssim(a, b) < 1
+    assert metrics.calculate_ssim(a, b) > metrics.calculate_ssim(a, a + 0.5 * rng.standard_normal(a.shape))
+
+
+def test_checkpoint_roundtrip_npz_and_pth(tmp_path):
+    sd = syn.make_state_dict(seed=5, dim_hidden=32, num_layers=2, latent_dim=16, siren_patch_size=8)
+    for name in ("m.npz", "m.pth"):
+        path = str(tmp_path / name)
+        weights.save_checkpoint(path, sd)
+        back = weights.load_checkpoint(path)
+        assert set(back) == set(sd)
+        assert all(np.array_equal(back[k], sd[k]) for k in sd)
+
+
+def test_model_object_protocol_without_gpu():
+    """Constructor kwargs, attribute names, state_dict protocol and error behaviour on a CPU-only host."""
+    from mri_inr_amd import ModulatedSiren
+
+    kw = dict(dim_in=2, dim_hidden=64, dim_out=1, num_layers=3, latent_dim=32, w0=1.0, w0_initial=30.0, use_bias=True,
+              dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None, outer_patch_size=32,
+              inner_patch_size=16, siren_patch_size=12, device="cuda", activation="morlet")
+    m = ModulatedSiren(**kw)
+    for attr in ("dim_hidden", "num_layers", "latent_dim", "siren_patch_size", "activation", "grid", "encoder_type",
+                 "outer_patch_size", "inner_patch_size", "modulate", "dim_out"):
+        assert hasattr(m, attr)
+    assert m.grid.shape == (144, 2)
+    sd = m.state_dict()
+    assert list(sd)[0] == "grid" and sd["net.layers.1.weight"].shape == (64, 64)
+    sd["net.layers.1.weight"] = np.zeros((64, 63), np.float32)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        m.load_state_dict(sd)
+    sd = m.state_dict()
+    sd["bogus"] = np.zeros(1, np.float32)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        m.load_state_dict(sd)
+    assert m.eval() is m and m.training is False
+    with pytest.raises(NotImplementedError):
+        m.train(True)
+    with pytest.raises(ValueError):
+        ModulatedSiren(**dict(kw, dim_out=3))
+    with pytest.raises(NotImplementedError):
+        ModulatedSiren(**dict(kw, encoder_type="vgg"))
+    # any other encoder_type builds (like the reference) but has no encoder: forward fails with AttributeError
+    m2 = ModulatedSiren(**dict(kw, encoder_type="default"))
+    assert not any(k.startswith("encoder.") for k in m2.state_dict())
+    with pytest.raises(AttributeError):
+        m2(np.zeros((1, 32, 32), np.float32))
