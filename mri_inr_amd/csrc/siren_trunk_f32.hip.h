@@ -45,11 +45,11 @@ struct TrunkParams {
     unsigned long long* stamps;  // diagnostic build only: [grid][32] s_memtime stamps
 };
 
-// sin(2*pi*r): exact fp32 range reduction to [0,1) (v_fract_f32), then the hardware sine, whose
-// argument is in revolutions (measured max abs error 1.25e-7, tools/sin_accuracy.hip).
-__device__ __forceinline__ float sin_rev(float r) {
-    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r));
-}
+// sin(2*pi*r) with the hardware sine, whose argument is in revolutions.  On gfx950 v_sin_f32 performs
+// the fractional range reduction itself and exactly: measured max abs error 1.25e-7 over [-32, 32]
+// (tools/sin_accuracy.hip) and exact results out to 2^20 revolutions (tools/sin_range_probe.hip), so no
+// explicit v_fract / v_rndne is spent on it.
+__device__ __forceinline__ float sin_rev(float r) { return __builtin_amdgcn_sinf(r); }
 
 template <int ACT>
 __device__ __forceinline__ float activate(float r, float cg) {
