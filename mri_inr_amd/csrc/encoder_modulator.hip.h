@@ -25,7 +25,9 @@ struct EncoderParams {
 __device__ __forceinline__ float leaky02(float x) { return x >= 0.f ? x : 0.2f * x; }
 
 // One workgroup (256 threads) per 32x32 tile; all intermediate feature maps live in LDS.
-__global__ __launch_bounds__(256) void encoder_kernel(EncoderParams p, const float* __restrict__ tiles, float* __restrict__ latent) {
+// launch_bounds(256, 5) caps the kernel at 96 VGPRs: with two streams its waves run BESIDE the persistent
+// trunk workgroup of the previous call, which leaves 104 registers per SIMD lane free.
+__global__ __launch_bounds__(256, 5) void encoder_kernel(EncoderParams p, const float* __restrict__ tiles, float* __restrict__ latent) {
     __shared__ float t0[33 * 33];       // input with a zero row/column in front (padding = 1)
     __shared__ float a1[16 * 17 * 17];  // conv1 output, same front padding for conv2
     __shared__ float a2[2048];          // conv2 output, flattened (c, y, x)

@@ -117,6 +117,9 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     const int c32 = lane & 31;
     const int L = p.L;
     const int nchunks = (L - 1) * 8;
+#ifdef MSIREN_CLAIM_RF
+    asm volatile("; claim the whole register file" ::: "v255", "a255");
+#endif
 
     // Per-lane byte bases of the LDS tables.  Every table access below is `base + compile-time
     // constant` so that it folds into the ds_read offset field: written as index arithmetic on the
@@ -198,16 +201,18 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     // bias / modulation / last_layer weight of the epilogue part in flight and of the next one
     // (two register sets, loaded one scheduling group ahead of their use)
     f32x4 tb_b[2], tb_m[2], tb_w[2];
-    auto tbl_load = [&](int set, const unsigned char* bl, const unsigned char* ml, const unsigned char* wo, int t, int g) {
+    auto tbl_load = [&](int set, const unsigned char* bl, const unsigned char* ml, const unsigned char* wo, int t, int g,
+                        bool withw) {
         const int fo = (32 * t + 8 * g) * 4;  // compile-time byte offset
         tb_b[set] = *reinterpret_cast<const f32x4*>(bl + fo);
         tb_m[set] = *reinterpret_cast<const f32x4*>(ml + fo);
-        tb_w[set] = *reinterpret_cast<const f32x4*>(wo + fo);
+        if (withw) tb_w[set] = *reinterpret_cast<const f32x4*>(wo + fo);
     };
     // half `hh` (elements 2hh, 2hh+1) of part g of an accumulator tile: acc -> (revolutions) -> activation
-    // -> modulation -> fp16 hi/lo pair; also accumulates last_layer's dot product (the weight table is
-    // all zeros except on the final hidden layer)
-    auto epi_half = [&](const f32x16& a, float winv, float cgl, int set, int g, int hh) {
+    // -> modulation, then either (lastl = false) the fp16 hi/lo pair for the next layer's B operand, or
+    // (lastl = true: final hidden layer, separate code instance) last_layer's dot product -- no split,
+    // no pack, no AGPR store there, and no dot-product FMA anywhere else.
+    auto epi_half = [&](const f32x16& a, float winv, float cgl, int set, int g, int hh, bool lastl) {
         // The two accumulator elements pass through an opaque asm: instruction selection orders pure
         // VALU code only by data dependence, so without an anchor the whole tile's epilogue is emitted
         // in one block ahead of the MFMAs and the sched_barrier-delimited groups are empty of VALU.
@@ -219,11 +224,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         for (int e = 0; e < 2; ++e) {
             const float r = __builtin_fmaf(ain[e], winv, tb_b[set][2 * hh + e]);
             v[e] = activate<ACT>(r, cgl) * tb_m[set][2 * hh + e];
-            part = __builtin_fmaf(v[e], tb_w[set][2 * hh + e], part);
+            if (lastl) part = __builtin_fmaf(v[e], tb_w[set][2 * hh + e], part);
         }
-        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-        eh[g][hh] = h;
-        el[g][hh] = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h[0], v[1] - (float)h[1]);
+        if (!lastl) {
+            const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+            eh[g][hh] = h;
+            el[g][hh] = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h[0], v[1] - (float)h[1]);
+        }
     };
     auto epi_store2 = [&](int ks, h8& dh, h8& dl) {  // k-step ks (0/1) of the tile = parts 2ks, 2ks+1
         dh = to_acc_file(pack_h8(eh[2 * ks][0], eh[2 * ks][1], eh[2 * ks + 1][0], eh[2 * ks + 1][1]));
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     } while (0)
 #endif
 
-#define MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, Q)                                          \
+#define MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, Q, LASTF)                                       \
     do {                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                    \
         if ((Q) >= 4) { /* two of the eight DMA pieces of chunk c+R-1 per group */            \
@@ -319,19 +326,19 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         if (MSIREN_ABL & 1) { /* keep the accumulators alive so the MFMAs are not dead code */  \
             if ((Q) == 0) asm volatile("" ::"v"(acc[((T) + 1) & 1]));                         \
         } else if ((T) == 0) {                                                                \
-            if ((Q) < 3) tbl_load(((Q) + 1) & 1, blp_, mlp_, zeroB, 7, ((Q) + 1) & 3);        \
+            if ((Q) < 3) tbl_load(((Q) + 1) & 1, blp_, mlp_, zeroB, 7, ((Q) + 1) & 3, false); \
             if ((Q) < 4) {                                                                    \
-                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 0);                            \
-                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 1);                            \
+                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 0, false);                     \
+                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 1, false);                     \
             }                                                                                 \
             if ((Q) == 4) epi_store2(0, INh[14], INl[14]);                                    \
             if ((Q) == 5) epi_store2(1, INh[15], INl[15]);                                    \
         } else {                                                                              \
-            if (((Q) & 1) == 1 && (Q) < 7) tbl_load((((Q) >> 1) + 1) & 1, bl_, ml_, wo_, ((T) + 7) & 7, (((Q) >> 1) + 1) & 3); \
-            epi_half(acc[((T) + 1) & 1], wi_, p.cg, ((Q) >> 1) & 1, (Q) >> 1, (Q) & 1);       \
-            if ((Q) == 5) epi_store2(0, OUTh[(2 * (T) + 14) & 15], OUTl[(2 * (T) + 14) & 15]); \
+            if (((Q) & 1) == 1 && (Q) < 7) tbl_load((((Q) >> 1) + 1) & 1, bl_, ml_, wo_, ((T) + 7) & 7, (((Q) >> 1) + 1) & 3, LASTF); \
+            epi_half(acc[((T) + 1) & 1], wi_, p.cg, ((Q) >> 1) & 1, (Q) >> 1, (Q) & 1, LASTF); \
+            if ((Q) == 5 && !(LASTF)) epi_store2(0, OUTh[(2 * (T) + 14) & 15], OUTl[(2 * (T) + 14) & 15]); \
         }                                                                                     \
-        if ((Q) == 7 && !(MSIREN_ABL & 1)) tbl_load(0, bl_, ml_, wo_, (T), 0); /* part 0 of THIS tile's epilogue (runs next tile) */ \
+        if ((Q) == 7 && !(MSIREN_ABL & 1)) tbl_load(0, bl_, ml_, wo_, (T), 0, LASTF); /* part 0 of THIS tile's epilogue (runs next tile) */ \
         MSIREN_F16_KSTEP(INh, INl, T, Q, 0);                                                  \
         MSIREN_F16_KSTEP(INh, INl, T, Q, 1);                                                  \
         /* requested issue order inside the region: the weight-fragment reads first, VALU spread */ \
@@ -342,27 +349,27 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     // every wave has finished the previous tile (so its buffer may be refilled: DMA of chunk c+R-1) and,
     // after the counted vmcnt + barrier, chunk c+1 is visible to all -- early enough for group 7 to
     // prefetch the next tile's first weight fragments, so no LDS latency is exposed at tile boundaries.
-#define MSIREN_F16_TILE(INh, INl, OUTh, OUTl, T)                                              \
+#define MSIREN_F16_TILE(INh, INl, OUTh, OUTl, T, LASTF)                                           \
     do {                                                                                      \
         const h8* ring_ = reinterpret_cast<const h8*>(smem + LY::ring + rd_buf * F16_CHUNK_BYTES) + lane; \
         rd_buf = rd_buf + 1 == R ? 0 : rd_buf + 1;                                            \
         const h8* ringn_ = reinterpret_cast<const h8*>(smem + LY::ring + rd_buf * F16_CHUNK_BYTES) + lane; \
-        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 0);                                         \
-        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 1);                                         \
-        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 2);                                         \
-        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 3);                                         \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 0, LASTF);                                    \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 1, LASTF);                                    \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 2, LASTF);                                    \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 3, LASTF);                                    \
         __builtin_amdgcn_sched_barrier(0);                                                    \
         if (!(MSIREN_ABL & 2)) {                                                              \
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 8) : "memory");                \
             __builtin_amdgcn_s_barrier();                                                     \
         }                                                                                     \
         dma_begin();                                                                          \
-        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 4);                                         \
-        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 5);                                         \
-        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 6);                                         \
-        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 7);                                         \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 4, LASTF);                                    \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 5, LASTF);                                    \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 6, LASTF);                                    \
+        MSIREN_F16_GROUP(INh, INl, OUTh, OUTl, T, 7, LASTF);                                    \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        if ((T) > 0 && !(MSIREN_ABL & 1)) epi_store2(1, OUTh[(2 * (T) + 15) & 15], OUTl[(2 * (T) + 15) & 15]); \
+        if ((T) > 0 && !(LASTF) && !(MSIREN_ABL & 1)) epi_store2(1, OUTh[(2 * (T) + 15) & 15], OUTl[(2 * (T) + 15) & 15]); \
         if constexpr (DBG) { stamp(8 + dbg_tile); ++dbg_tile; }                               \
     } while (0)
 
@@ -370,24 +377,24 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     // (which produces IN[14], IN[15]) is issued inside this layer's first tile.  For l_ == 1 the
     // "previous layer" is layer 0, whose arguments were left in acc[1] in revolutions: inverse scale 1,
     // no bias, layer-0 modulation and Morlet constant.
-#define MSIREN_F16_LAYER(INh, INl, OUTh, OUTl, LIDX)                                          \
+#define MSIREN_F16_LAYER(INh, INl, OUTh, OUTl, LIDX, LASTF)                                       \
     do {                                                                                      \
         const int l_ = (LIDX);                                                                \
-        const unsigned char* wo_ = (l_ == L - 1) ? woutB : zeroB;                             \
+        const unsigned char* wo_ = woutB; /* read by the final-layer instance only */         \
         const unsigned char* bl_ = biasB + (l_ - 1) * 1024;                                   \
         const unsigned char* ml_ = modB + l_ * 1024;                                          \
         const unsigned char* blp_ = l_ > 1 ? biasB + (l_ - 2) * 1024 : zeroB;                 \
         const unsigned char* mlp_ = modB + (l_ - 1) * 1024;                                   \
         const float wi_ = winvT[l_ - 1], wip_ = l_ > 1 ? winvT[l_ - 2] : 1.0f;              \
         const float cgp_ = l_ > 1 ? p.cg : p.cg0;                                             \
-        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 0);                                             \
-        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 1);                                             \
-        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 2);                                             \
-        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 3);                                             \
-        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 4);                                             \
-        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 5);                                             \
-        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 6);                                             \
-        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 7);                                             \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 0, LASTF);                                        \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 1, LASTF);                                        \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 2, LASTF);                                        \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 3, LASTF);                                        \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 4, LASTF);                                        \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 5, LASTF);                                        \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 6, LASTF);                                        \
+        MSIREN_F16_TILE(INh, INl, OUTh, OUTl, 7, LASTF);                                        \
     } while (0)
 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 8) : "memory");
@@ -469,22 +476,34 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
                 }
             acc[1] = r7;
         }
-        tbl_load(0, zeroB, modB, zeroB, 7, 0);  // part 0 of the layer-0 "pending" tile
+        tbl_load(0, zeroB, modB, zeroB, 7, 0, false);  // part 0 of the layer-0 "pending" tile
 
         part = 0.f;
         stamp(1);
-        for (int l = 1; l < L; l += 2) {
-            MSIREN_F16_LAYER(Xh, Xl, Yh, Yl, l);
-            stamp(l == 1 ? 2 : 4);
-            if (l + 1 < L) MSIREN_F16_LAYER(Yh, Yl, Xh, Xl, l + 1);
-            stamp(l == 1 ? 3 : 5);
+        // Hidden layers alternate X->Y (instance A) and Y->X (instance B); the final hidden layer has its own
+        // instances (no fp16 split / AGPR store, the only place the last_layer dot product is accumulated),
+        // one per input array.  Straight-line data flow: no merge points for the register-resident arrays.
+        for (int l = 1;;) {
+            if (l == L - 1) {
+                MSIREN_F16_LAYER(Xh, Xl, Yh, Yl, l, true);
+                break;
+            }
+            MSIREN_F16_LAYER(Xh, Xl, Yh, Yl, l, false);
+            ++l;
+            if (l == L - 1) {
+                MSIREN_F16_LAYER(Yh, Yl, Xh, Xl, l, true);
+                break;
+            }
+            MSIREN_F16_LAYER(Yh, Yl, Xh, Xl, l, false);
+            ++l;
         }
-        // the final hidden layer's last tile is still pending: only its contribution to `part` matters
+        stamp(2);
+        // the final hidden layer's last tile is still pending: its contribution to `part`
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (g > 0) tbl_load(g & 1, biasB + (L - 2) * 1024, modB + (L - 1) * 1024, woutB, 7, g);
-            epi_half(acc[1], winvT[L - 2], p.cg, g & 1, g, 0);
-            epi_half(acc[1], winvT[L - 2], p.cg, g & 1, g, 1);
+            if (g > 0) tbl_load(g & 1, biasB + (L - 2) * 1024, modB + (L - 1) * 1024, woutB, 7, g, true);
+            epi_half(acc[1], winvT[L - 2], p.cg, g & 1, g, 0, true);
+            epi_half(acc[1], winvT[L - 2], p.cg, g & 1, g, 1, true);
         }
         part += __shfl_xor(part, 32);
         if (pvalid && half == 0) p.out[(size_t)b * p.P + pc] = sin_rev(part + p.bout);
