@@ -172,15 +172,18 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
 
     unsigned ew[4][2];  // packed output pairs of the tile being finished: [part][half]
     hf4 tb_b[2], tb_m[2], tb_w[2];
-    auto tbl_load = [&](int set, const unsigned char* bl, const unsigned char* ml, const unsigned char* wo, int t, int g) {
+    auto tbl_load = [&](int set, const unsigned char* bl, const unsigned char* ml, const unsigned char* wo, int t, int g,
+                        bool withw) {
         const int fo = (32 * t + 8 * g) * 2;  // compile-time byte offset (fp16)
         tb_b[set] = *reinterpret_cast<const hf4*>(bl + fo);
         tb_m[set] = *reinterpret_cast<const hf4*>(ml + fo);
-        tb_w[set] = *reinterpret_cast<const hf4*>(wo + fo);
+        if (withw) tb_w[set] = *reinterpret_cast<const hf4*>(wo + fo);
     };
     // half `hh` (elements 2hh, 2hh+1) of part g; `old` = the fragment that holds the same features of the
     // layer's INPUT (word 2(g&1)+hh), `rflag` = 1 where the residual applies (0 for the layer-0 tile)
-    auto epi_half = [&](const f32x16& a, float winv, float cgl, int set, int g, int hh, const u32x4& old, float rflag) {
+    // lastl = final hidden layer (own code instances): accumulate last_layer's dot product, produce no fragment
+    auto epi_half = [&](const f32x16& a, float winv, float cgl, int set, int g, int hh, const u32x4& old, float rflag,
+                        bool lastl) {
         float a0 = a[4 * g + 2 * hh], a1 = a[4 * g + 2 * hh + 1];
         asm volatile("; epilogue slice anchored to its MFMA group" : "+v"(a0), "+v"(a1));
         const float ain[2] = {a0, a1};
@@ -192,9 +195,9 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
             const float r = __builtin_fmaf(ain[e], winv, (float)tb_b[set][2 * hh + e]);
             v[e] = activate<ACT>(r, cgl) * (float)tb_m[set][2 * hh + e];
             if constexpr (RES) v[e] = __builtin_fmaf(xo[e], rflag, v[e]);
-            part = __builtin_fmaf(v[e], (float)tb_w[set][2 * hh + e], part);
+            if (lastl) part = __builtin_fmaf(v[e], (float)tb_w[set][2 * hh + e], part);
         }
-        ew[g][hh] = x1_pack2<BF>(v[0], v[1]);
+        if (!lastl) ew[g][hh] = x1_pack2<BF>(v[0], v[1]);
     };
     auto epi_store1 = [&](int ks, u32x4& d) {  // k-step ks (0/1) of the tile = parts 2ks, 2ks+1
         u32x4 u;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
     };
     u32x4 wf_[2][4];
 
-#define MSIREN_X1_GROUP(IN, OUT, T, Q)                                                        \
+#define MSIREN_X1_GROUP(IN, OUT, T, Q, LASTF)                                                  \
     do {                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                    \
         {                                                                                     \
@@ -218,20 +221,20 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
         }                                                                                     \
         if ((T) == 0) {                                                                       \
             /* pending tile 15 of the previous layer: its input fragments are OUT[30], OUT[31] */ \
-            if ((Q) < 3) tbl_load(((Q) + 1) & 1, blp_, mlp_, zeroB, 15, ((Q) + 1) & 3);       \
+            if ((Q) < 3) tbl_load(((Q) + 1) & 1, blp_, mlp_, zeroB, 15, ((Q) + 1) & 3, false); \
             if ((Q) < 4) {                                                                    \
-                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 0, OUT[30 + (((Q) & 3) >> 1)], rfp_); \
-                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 1, OUT[30 + (((Q) & 3) >> 1)], rfp_); \
+                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 0, OUT[30 + (((Q) & 3) >> 1)], rfp_, false); \
+                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 1, OUT[30 + (((Q) & 3) >> 1)], rfp_, false); \
             }                                                                                 \
             if ((Q) == 4) epi_store1(0, IN[30]);                                              \
             if ((Q) == 5) epi_store1(1, IN[31]);                                              \
         } else {                                                                              \
-            if (((Q) & 1) == 1 && (Q) < 7) tbl_load((((Q) >> 1) + 1) & 1, bl_, ml_, wo_, ((T) + 15) & 15, (((Q) >> 1) + 1) & 3); \
+            if (((Q) & 1) == 1 && (Q) < 7) tbl_load((((Q) >> 1) + 1) & 1, bl_, ml_, wo_, ((T) + 15) & 15, (((Q) >> 1) + 1) & 3, LASTF); \
             epi_half(acc[((T) + 1) & 1], wi_, p.cg, ((Q) >> 1) & 1, (Q) >> 1, (Q) & 1,       \
-                     IN[(2 * (T) + 30 + ((Q) >> 2)) & 31], 1.0f);                             \
-            if ((Q) == 5) epi_store1(0, OUT[(2 * (T) + 30) & 31]);                            \
+                     IN[(2 * (T) + 30 + ((Q) >> 2)) & 31], 1.0f, LASTF);                      \
+            if ((Q) == 5 && !(LASTF)) epi_store1(0, OUT[(2 * (T) + 30) & 31]);                \
         }                                                                                     \
-        if ((Q) == 7) tbl_load(0, bl_, ml_, wo_, (T), 0);                                     \
+        if ((Q) == 7) tbl_load(0, bl_, ml_, wo_, (T), 0, LASTF);                              \
         x1_mfma<BF>(acc[(T) & 1], wf_[(Q) & 1][0], IN[4 * (Q) + 0], (Q) == 0);                \
         x1_mfma<BF>(acc[(T) & 1], wf_[(Q) & 1][1], IN[4 * (Q) + 1], false);                   \
         x1_mfma<BF>(acc[(T) & 1], wf_[(Q) & 1][2], IN[4 * (Q) + 2], false);                   \
@@ -250,31 +253,46 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
         __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                    \
     } while (0)
 
-#define MSIREN_X1_TILE(IN, OUT, T)                                                            \
+#define MSIREN_X1_TILE(IN, OUT, T, LASTF)                                                      \
     do {                                                                                      \
         const u32x4* ring_ = reinterpret_cast<const u32x4*>(smem + LY::ring + rd_buf * X1_CHUNK_BYTES) + lane; \
         rd_buf = rd_buf + 1 == R ? 0 : rd_buf + 1;                                            \
         const u32x4* ringn_ = reinterpret_cast<const u32x4*>(smem + LY::ring + rd_buf * X1_CHUNK_BYTES) + lane; \
-        MSIREN_X1_GROUP(IN, OUT, T, 0);                                                       \
-        MSIREN_X1_GROUP(IN, OUT, T, 1);                                                       \
-        MSIREN_X1_GROUP(IN, OUT, T, 2);                                                       \
-        MSIREN_X1_GROUP(IN, OUT, T, 3);                                                       \
+        MSIREN_X1_GROUP(IN, OUT, T, 0, LASTF);                                                  \
+        MSIREN_X1_GROUP(IN, OUT, T, 1, LASTF);                                                  \
+        MSIREN_X1_GROUP(IN, OUT, T, 2, LASTF);                                                  \
+        MSIREN_X1_GROUP(IN, OUT, T, 3, LASTF);                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                    \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 8) : "memory");                    \
         __builtin_amdgcn_s_barrier();                                                         \
         dma_next();                                                                           \
-        MSIREN_X1_GROUP(IN, OUT, T, 4);                                                       \
-        MSIREN_X1_GROUP(IN, OUT, T, 5);                                                       \
-        MSIREN_X1_GROUP(IN, OUT, T, 6);                                                       \
-        MSIREN_X1_GROUP(IN, OUT, T, 7);                                                       \
+        MSIREN_X1_GROUP(IN, OUT, T, 4, LASTF);                                                  \
+        MSIREN_X1_GROUP(IN, OUT, T, 5, LASTF);                                                  \
+        MSIREN_X1_GROUP(IN, OUT, T, 6, LASTF);                                                  \
+        MSIREN_X1_GROUP(IN, OUT, T, 7, LASTF);                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        if ((T) > 0) epi_store1(1, OUT[(2 * (T) + 31) & 31]);                                 \
+        if ((T) > 0 && !(LASTF)) epi_store1(1, OUT[(2 * (T) + 31) & 31]);                     \
     } while (0)
 
-#define MSIREN_X1_LAYER(IN, OUT, LIDX)                                                        \
+// final hidden layer's last tile: only `part` matters; its residual input sits in the array that layer read (IN)
+#define MSIREN_X1_FINAL(IN)                                                                          \
+    {                                                                                                \
+        MSIREN_X1_FINAL_G(IN, 0);                                                                    \
+        MSIREN_X1_FINAL_G(IN, 1);                                                                    \
+        MSIREN_X1_FINAL_G(IN, 2);                                                                    \
+        MSIREN_X1_FINAL_G(IN, 3);                                                                    \
+    }
+#define MSIREN_X1_FINAL_G(IN, G)                                                                     \
+    {                                                                                                \
+        if ((G) > 0) tbl_load((G) & 1, biasB + (L - 2) * 1024, modB + (L - 1) * 1024, woutB, 15, (G), true); \
+        epi_half(acc[1], winvT[L - 2], p.cg, (G) & 1, (G), 0, IN[30 + ((G) >> 1)], 1.0f, true);      \
+        epi_half(acc[1], winvT[L - 2], p.cg, (G) & 1, (G), 1, IN[30 + ((G) >> 1)], 1.0f, true);      \
+    }
+
+#define MSIREN_X1_LAYER(IN, OUT, LIDX, LASTF)                                                  \
     do {                                                                                      \
         const int l_ = (LIDX);                                                                \
-        const unsigned char* wo_ = (l_ == L - 1) ? woutB : zeroB;                             \
+        const unsigned char* wo_ = woutB; /* read by the final-layer instances only */        \
         const unsigned char* bl_ = biasB + (l_ - 1) * 1024;                                   \
         const unsigned char* ml_ = modB + l_ * 1024;                                          \
         const unsigned char* blp_ = l_ > 1 ? biasB + (l_ - 2) * 1024 : zeroB;                 \
@@ -282,22 +300,22 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
         const float wi_ = winvT[l_ - 1], wip_ = l_ > 1 ? winvT[l_ - 2] : 1.0f;              \
         const float cgp_ = l_ > 1 ? p.cg : p.cg0;                                             \
         const float rfp_ = l_ > 1 ? 1.0f : 0.0f; /* layer 0 has no skip connection */         \
-        MSIREN_X1_TILE(IN, OUT, 0);                                                           \
-        MSIREN_X1_TILE(IN, OUT, 1);                                                           \
-        MSIREN_X1_TILE(IN, OUT, 2);                                                           \
-        MSIREN_X1_TILE(IN, OUT, 3);                                                           \
-        MSIREN_X1_TILE(IN, OUT, 4);                                                           \
-        MSIREN_X1_TILE(IN, OUT, 5);                                                           \
-        MSIREN_X1_TILE(IN, OUT, 6);                                                           \
-        MSIREN_X1_TILE(IN, OUT, 7);                                                           \
-        MSIREN_X1_TILE(IN, OUT, 8);                                                           \
-        MSIREN_X1_TILE(IN, OUT, 9);                                                           \
-        MSIREN_X1_TILE(IN, OUT, 10);                                                          \
-        MSIREN_X1_TILE(IN, OUT, 11);                                                          \
-        MSIREN_X1_TILE(IN, OUT, 12);                                                          \
-        MSIREN_X1_TILE(IN, OUT, 13);                                                          \
-        MSIREN_X1_TILE(IN, OUT, 14);                                                          \
-        MSIREN_X1_TILE(IN, OUT, 15);                                                          \
+        MSIREN_X1_TILE(IN, OUT, 0, LASTF);                                                           \
+        MSIREN_X1_TILE(IN, OUT, 1, LASTF);                                                           \
+        MSIREN_X1_TILE(IN, OUT, 2, LASTF);                                                           \
+        MSIREN_X1_TILE(IN, OUT, 3, LASTF);                                                           \
+        MSIREN_X1_TILE(IN, OUT, 4, LASTF);                                                           \
+        MSIREN_X1_TILE(IN, OUT, 5, LASTF);                                                           \
+        MSIREN_X1_TILE(IN, OUT, 6, LASTF);                                                           \
+        MSIREN_X1_TILE(IN, OUT, 7, LASTF);                                                           \
+        MSIREN_X1_TILE(IN, OUT, 8, LASTF);                                                           \
+        MSIREN_X1_TILE(IN, OUT, 9, LASTF);                                                           \
+        MSIREN_X1_TILE(IN, OUT, 10, LASTF);                                                          \
+        MSIREN_X1_TILE(IN, OUT, 11, LASTF);                                                          \
+        MSIREN_X1_TILE(IN, OUT, 12, LASTF);                                                          \
+        MSIREN_X1_TILE(IN, OUT, 13, LASTF);                                                          \
+        MSIREN_X1_TILE(IN, OUT, 14, LASTF);                                                          \
+        MSIREN_X1_TILE(IN, OUT, 15, LASTF);                                                          \
     } while (0)
 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 8) : "memory");
@@ -373,26 +391,25 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
                 }
             acc[1] = r7;
         }
-        tbl_load(0, zeroB, modB, zeroB, 15, 0);
+        tbl_load(0, zeroB, modB, zeroB, 15, 0, false);
 
         part = 0.f;
-        for (int l = 1; l < L; l += 2) {
-            MSIREN_X1_LAYER(X, Y, l);
-            if (l + 1 < L) MSIREN_X1_LAYER(Y, X, l + 1);
-        }
-        // final hidden layer's last tile: only `part` matters; its residual input is in the array the
-        // last layer read from (X if the number of hidden layers is odd, else Y)
-        {
-            const bool odd = ((L - 1) & 1) != 0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g > 0) tbl_load(g & 1, biasB + (L - 2) * 1024, modB + (L - 1) * 1024, woutB, 15, g);
-                u32x4 old;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) old[w] = odd ? X[30 + (g >> 1)][w] : Y[30 + (g >> 1)][w];
-                epi_half(acc[1], winvT[L - 2], p.cg, g & 1, g, 0, old, 1.0f);
-                epi_half(acc[1], winvT[L - 2], p.cg, g & 1, g, 1, old, 1.0f);
+        // hidden layers alternate X->Y / Y->X; the final hidden layer has its own instances (one per input array)
+        for (int l = 1;;) {
+            if (l == L - 1) {
+                MSIREN_X1_LAYER(X, Y, l, true);
+                MSIREN_X1_FINAL(X);
+                break;
             }
+            MSIREN_X1_LAYER(X, Y, l, false);
+            ++l;
+            if (l == L - 1) {
+                MSIREN_X1_LAYER(Y, X, l, true);
+                MSIREN_X1_FINAL(Y);
+                break;
+            }
+            MSIREN_X1_LAYER(Y, X, l, false);
+            ++l;
         }
         part += __shfl_xor(part, 32);
         if (pvalid && half == 0) p.out[(size_t)b * p.P + pc] = sin_rev(part + p.bout);
