@@ -47,6 +47,9 @@ def parse():
                          "(default); fp32 = v_mfma_f32_32x32x2_f32")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = consecutive steps alternate between two HIP streams (independent slices overlap)")
+    ap.add_argument("--pipeline", default="forward", choices=["forward", "reconstruct"],
+                    help="forward = ModulatedSiren.forward on resident tiles (the metric's timed region); "
+                         "reconstruct = slice -> tiles -> black filter -> forward -> weighted fold -> slice, all on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--check", action="store_true", help="also verify one batch against the oracle")
@@ -167,6 +170,7 @@ def main():
     d_tiles = model.device_array((B, 32, 32))
     d_outs = [model.device_array((B, 24, 24)) for _ in range(2)]
     d_out = d_outs[0]
+    d_recons = [model.device_array((n_sl, 320, 320)) for _ in range(2)] if args.pipeline == "reconstruct" else None
     _lib.check(lib.msiren_set_streams(h, args.streams))
     _lib.check(lib.msiren_image_to_patches_dev(h, d_img.ptr, n_sl, 320, 320, d_tiles.ptr))
     model.sync()
@@ -175,7 +179,10 @@ def main():
 
     def step():
         # consecutive steps are independent slices: alternate the output buffer with the stream
-        _lib.check(lib.msiren_forward_tiles_dev(h, d_tiles.ptr, B, d_outs[nstep[0] & 1].ptr))
+        if d_recons is not None:
+            _lib.check(lib.msiren_reconstruct_slices_dev(h, d_img.ptr, n_sl, 320, 320, d_recons[nstep[0] & 1].ptr))
+        else:
+            _lib.check(lib.msiren_forward_tiles_dev(h, d_tiles.ptr, B, d_outs[nstep[0] & 1].ptr))
         nstep[0] += 1
 
     def fence():
@@ -253,6 +260,7 @@ def main():
                         "tiles and outputs resident in HBM",
             "slices_per_gpu_per_step": n_sl, "patches_per_step_per_gpu": B, "coords_per_patch": 576,
             "dim_hidden": H, "num_layers": L, "latent_dim": Z, "residual": deep, "activation": args.activation, "precision": args.precision, "streams": args.streams,
+            "pipeline": args.pipeline,
             "parallelism": f"patch-shard x{world}",
         },
         "roofline": {
@@ -271,7 +279,13 @@ def main():
     }
 
     if rank == 0:
-        if args.check:
+        if args.check and d_recons is not None:
+            from oracle import siren_oracle as orc
+
+            ref = orc.reconstruct_slice(sd, imgs[0], num_layers=L, activation=args.activation, dtype=np.float64)
+            got = d_recons[(nstep[0] - 1) & 1].numpy()[0]
+            result["check_nerr_vs_fp64_oracle"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+        elif args.check:
             from oracle import siren_oracle as orc
 
             got = d_out.numpy()[:64]

@@ -5,6 +5,7 @@ Gate: max|gpu - ref| / max|ref| <= 1e-4 and RM
 fp32 configurations.  The oracle is the checker only; nothing here feeds it into the product.
 """
 import json
+import os
 
 import numpy as np
 import pytest
@@ -415,3 +416,44 @@ def test_deep_model_falls_back_to_fp32_trunk():
     e32 = nerr(orc.siren_forward(sd, mods, num_layers=L), ref)
     e = nerr(m.forward_mods(mods).reshape(3, -1), ref)
     assert e <= max(1e-4, 10 * e32), (e, e32)
+
+
+def test_rccl_broadcast_then_forward_single_rank():
+    """The N > 1 bench path with the real backend: init RCCL ("nccl"), broadcast the weight blob through a
+    device tensor, load it into the HIP library of the same process and evaluate.  world_size 1 (one
+    card here); the 2-rank logic is covered on gloo in test_dist_gloo.py."""
+    import subprocess
+    import sys
+    import textwrap
+
+    script = textwrap.dedent("""
+        import os, sys, numpy as np
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
+        import torch, torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from mri_inr_amd import ModulatedSiren, synthetic as syn
+        from mri_inr_amd.dist import broadcast_state_dict
+        from oracle import siren_oracle as orc
+        sd0 = syn.make_state_dict(seed=3, trained_like=True)
+        sd = broadcast_state_dict(sd0, src=0, device=torch.device("cuda", 0))
+        assert all(np.array_equal(sd[k], sd0[k]) for k in sd0)
+        m = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
+                           use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                           outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda:0",
+                           activation="sine")
+        m.load_state_dict(sd); m.to("cuda:0").eval()
+        tiles = np.random.default_rng(0).random((16, 32, 32), dtype=np.float32)
+        out = np.asarray(m(tiles))
+        ref = orc.modulated_siren_forward(sd, tiles, num_layers=5, dtype=np.float64)
+        err = float(np.abs(out - ref).max() / np.abs(ref).max())
+        t = torch.tensor([err], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier(); torch.cuda.synchronize()
+        dist.destroy_process_group()
+        print("NERR", float(t.item()))
+        sys.exit(0 if float(t.item()) < 1e-4 else 1)
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", script], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "NERR" in r.stdout
