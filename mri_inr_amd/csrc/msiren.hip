@@ -333,7 +333,7 @@ int pack_trunk_x1(msiren_ctx* h) {
     const bool bf = h->cfg.precision == MSIREN_PREC_BF16;
     if (!(h->cfg.precision == MSIREN_PREC_BF16 || h->cfg.precision == MSIREN_PREC_F16)) return 0;
     if (H != 512 || L < 2 || L > 65 || msiren::X1Lds<3>::total(L) > 160 * 1024)
-        return fail(MSIREN_E_INVALID, "precision bf16/f16 (single-product register-resident trunk) needs dim_hidden = 512 and 2 <= num_layers <= 12; got H=%d L=%d", H, L);
+        return fail(MSIREN_E_INVALID, "precision bf16/f16 (single-product register-resident trunk) needs dim_hidden = 512 and 2 <= num_layers with its tables fitting the 160 KB LDS; got H=%d L=%d", H, L);
     const double two_pi = 6.283185307179586476925286766559;
     const double c = (double)h->cfg.w0 / two_pi, c0 = (double)h->cfg.w0_initial / two_pi;
     std::vector<uint16_t> wp((size_t)(L - 1) * 16 * 32 * 64 * 8), bias((size_t)(L - 1) * 512, 0), wout(512, 0);
@@ -661,25 +661,33 @@ bool use_f16x3(msiren_ctx* h) {
            msiren::F16Lds<3>::total(h->L) <= 160 * 1024;
 }
 
+// msiren_profile_enable: a HIP event pair around every trunk launch, on the stream it is launched on
+int profile_begin(msiren_ctx* h, hipEvent_t* end_event) {
+    *end_event = nullptr;
+    if (!h->profile) return 0;
+    if (h->prof_used == h->prof_events.size()) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        h->prof_events.emplace_back(a, b);
+    }
+    HIPCHK(hipEventRecord(h->prof_events[h->prof_used].first, h->sc[h->cur].s));
+    *end_event = h->prof_events[h->prof_used].second;
+    h->prof_used++;
+    return 0;
+}
+
 int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     if (B == 0) return 0;
     if (use_f16x3(h) || h->x1_ready) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->profile) {
-            if (h->prof_used == h->prof_events.size()) {
-                hipEvent_t a, b2;
-                HIPCHK(hipEventCreate(&a));
-                HIPCHK(hipEventCreate(&b2));
-                h->prof_events.emplace_back(a, b2);
-            }
-            e0 = h->prof_events[h->prof_used].first;
-            e1 = h->prof_events[h->prof_used].second;
-            h->prof_used++;
-            HIPCHK(hipEventRecord(e0, h->sc[h->cur].s));
+        hipEvent_t e1 = nullptr;
+        {
+            int rc = profile_begin(h, &e1);
+            if (rc) return rc;
         }
         int rc = h->x1_ready ? launch_trunk_x1(h, mods_dev, B, out_dev) : launch_trunk_f16x3(h, mods_dev, B, out_dev);
         if (rc) return rc;
-        if (h->profile) HIPCHK(hipEventRecord(e1, h->sc[h->cur].s));
+        if (e1) HIPCHK(hipEventRecord(e1, h->sc[h->cur].s));
         return 0;
     }
     const int chunks = (h->P + 63) / 64;
@@ -699,20 +707,9 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
     msiren::TrunkParams p = make_trunk_params(h, mods, stride, B, out_dev);
     const int grid = (int)(B * chunks);
 
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profile) {
-        if (h->prof_used == h->prof_events.size()) {
-            hipEvent_t a, b2;
-            HIPCHK(hipEventCreate(&a));
-            HIPCHK(hipEventCreate(&b2));
-            h->prof_events.emplace_back(a, b2);
-        }
-        e0 = h->prof_events[h->prof_used].first;
-        e1 = h->prof_events[h->prof_used].second;
-        h->prof_used++;
-        HIPCHK(hipEventRecord(e0, h->sc[h->cur].s));
-    }
-    int rc;
+    hipEvent_t e1 = nullptr;
+    int rc = profile_begin(h, &e1);
+    if (rc) return rc;
     switch (h->HP) {
         case 128: rc = launch_trunk_hp<128>(h, p, grid); break;
         case 256: rc = launch_trunk_hp<256>(h, p, grid); break;
@@ -721,7 +718,7 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
         default: return fail(MSIREN_E_INVALID, "dim_hidden=%d (padded %d) is not supported by the fp32 trunk (max 512)", h->H, h->HP);
     }
     if (rc) return rc;
-    if (h->profile) HIPCHK(hipEventRecord(e1, h->sc[h->cur].s));
+    if (e1) HIPCHK(hipEventRecord(e1, h->sc[h->cur].s));
     return 0;
 }
 
@@ -873,7 +870,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
-        delete h;
+        msiren_destroy(h);  // releases whatever was created
         return fail(MSIREN_E_HIP, "context creation failed: %s", hipGetErrorString(e));
     }
     *out = h;
@@ -1045,10 +1042,9 @@ int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev, int64_t n,
     return 0;
 }
 
-int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int64_t n, int32_t height, int32_t width, float* recon_dev) {
-    int rc = check(h);
-    if (rc) return rc;
-    next_stream(h);
+// slice pipeline on the CURRENT stream (the host-pointer entry point enqueues its copies around it)
+static int reconstruct_on_current_stream(msiren_handle h, const float* images_dev, int64_t n, int32_t height, int32_t width, float* recon_dev) {
+    int rc;
     if (n < 0 || (n > 0 && (!images_dev || !recon_dev))) return fail(MSIREN_E_INVALID, "bad arguments");
     if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles, outer_patch_size=%d", h->O);
     if (n == 0) return 0;
@@ -1079,6 +1075,13 @@ int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int6
     return 0;
 }
 
+int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int64_t n, int32_t height, int32_t width, float* recon_dev) {
+    int rc = check(h);
+    if (rc) return rc;
+    next_stream(h);
+    return reconstruct_on_current_stream(h, images_dev, n, height, width, recon_dev);
+}
+
 int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t n, int32_t height, int32_t width, float* recon_host) {
     int rc = check(h);
     if (rc) return rc;
@@ -1090,7 +1093,7 @@ int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t
     const size_t nr = (size_t)n * nV * h->I * nH * h->I * sizeof(float);
     if ((rc = ensure(h, h->ws_in, ni)) || (rc = ensure(h, h->ws_img, nr))) return rc;
     HIPCHK(hipMemcpyAsync(h->ws_in.p, images_host, ni, hipMemcpyHostToDevice, h->sc[h->cur].s));
-    if ((rc = msiren_reconstruct_slices_dev(h, (const float*)h->ws_in.p, n, height, width, (float*)h->ws_img.p))) return rc;
+    if ((rc = reconstruct_on_current_stream(h, (const float*)h->ws_in.p, n, height, width, (float*)h->ws_img.p))) return rc;
     HIPCHK(hipMemcpyAsync(recon_host, h->ws_img.p, nr, hipMemcpyDeviceToHost, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
     return 0;

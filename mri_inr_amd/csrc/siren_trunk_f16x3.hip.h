@@ -46,7 +46,7 @@ struct TrunkF16Params {
     float bout, cg0, cg;
     int B, P, L, units_per_patch, total_units;
     int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
-    unsigned pass_base;        // work queue: next pass id; the host sets it to gridDim.x before every launch
+    unsigned pass_base;        // value of *pass_counter when this launch starts (arithmetic is modulo 2^32)
     unsigned long long* stamps; // diagnostic instantiation only: [grid][8 passes][8] s_memtime + realtime
 };
 

@@ -272,6 +272,8 @@ def test_two_stream_pipelining_is_bit_identical():
         m = make_model(sd, precision=prec)
         tiles = [np.random.default_rng(s).random((37 + 11 * s, 32, 32), dtype=np.float32) for s in range(6)]
         ref = [m(t) for t in tiles]
+        img = syn.make_slice(5, brain_mask=True)
+        ref_img = m.reconstruct(img)
         d_in = [m.device_array(t.shape).copy_from(t) for t in tiles]
         d_out = [m.device_array((t.shape[0], 24, 24)) for t in tiles]
         _lib.check(m._lib.msiren_set_streams(m._h, 2))
@@ -281,6 +283,10 @@ def test_two_stream_pipelining_is_bit_identical():
         m.sync()
         for r, b in zip(ref, d_out):
             assert np.array_equal(r, b.numpy())
+        # host-pointer entry points stay self-contained (copies and kernels on one stream) in this mode
+        for _ in range(3):
+            assert np.array_equal(m.reconstruct(img), ref_img)
+            assert np.array_equal(m(tiles[0]), ref[0])
         _lib.check(m._lib.msiren_set_streams(m._h, 1))
 
 
