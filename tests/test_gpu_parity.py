@@ -189,6 +189,29 @@ def test_linearity_free_property_full_size():
     assert np.abs(full).max() <= 1.0
 
 
+def test_config3_full_size_batch_invariance():
+    """BASELINE configs[2] size (64 slices = 25 600 tiles in one call), default (f16x3, work-queue) trunk:
+    the batch is 64 shuffled copies of one slice's 400 tiles, so every output must equal -- bit for bit --
+    the output of the same tile in the 400-tile call, which itself is checked against the fp64 oracle."""
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = make_model(sd, precision="auto")
+    img = syn.make_slice(3)
+    tiles, _ = orc.image_to_patches(img, 32, 16)
+    base = m(tiles)
+    ref = orc.modulated_siren_forward(sd, tiles[:48], num_layers=5, dtype=np.float64)
+    check(base[:48], ref)
+    idx = np.concatenate([np.random.default_rng(k).permutation(400) for k in range(64)])
+    big = m(tiles[idx])
+    assert big.shape == (25600, 24, 24)
+    assert np.array_equal(big, base[idx])
+    # the slice pipeline at the same size: 64 slices in one call == each slice on its own
+    imgs = np.stack([syn.make_slice(k, brain_mask=(k % 2 == 0)) for k in range(64)])
+    rec = m.reconstruct(imgs)
+    assert rec.shape == (64, 320, 320)
+    for k in (0, 1, 31, 63):
+        assert np.array_equal(rec[k], m.reconstruct(imgs[k]))
+
+
 @pytest.mark.parametrize("H,Z,L,B", [(256, 256, 5, 400), (256, 256, 5, 3), (64, 48, 3, 17), (100, 24, 2, 5)])
 def test_modulator_kernels_vs_oracle(H, Z, L, B):
     """latent -> mods on the device (MFMA kernel when H, Z are multiples of 16, VALU kernel otherwise)."""
