@@ -3,8 +3,10 @@
 // Reference: src/networks/encoding/siren_encoder.py:503-512,565-577 (three convolutions with
 // LeakyReLU(0.2) + Linear(64, Z)) and src/networks/modulated_siren.py:325-343 (L x Linear+ReLU with
 // the latent re-concatenated, hidden first).  Together they are 2.1 MFLOP per patch against the
-// trunk's 303 MFLOP, so these are plain fp32 VALU kernels organised for coalesced weight reads and
-// LDS-resident activations, not MFMA kernels.
+// trunk's 303 MFLOP.  The two small convolutions run per tile on the VALU with LDS-resident feature
+// maps; everything that is a Linear layer over the batch (conv3 == Linear(2048, 64), the encoder's
+// Linear(64, Z), the modulator layers) runs as an exact-fp32 MFMA GEMM so that weights are read once
+// per 16 patches instead of once per patch.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -102,6 +104,56 @@ __global__ __launch_bounds__(256, 5) void encoder_kernel(EncoderParams p, const 
     }
 }
 
+// conv1 + conv2 of the encoder only: one workgroup per tile, writes the flattened conv2 output
+// (c, y, x) -> feat[tile][2048]; conv3 and the Linear follow as batched MFMA GEMMs (linear_mfma_kernel).
+__global__ __launch_bounds__(256, 5) void encoder_conv_kernel(EncoderParams p, const float* __restrict__ tiles, float* __restrict__ feat) {
+    __shared__ float t0[33 * 33];       // input with a zero row/column in front (padding = 1)
+    __shared__ float a1[16 * 17 * 17];  // conv1 output, same front padding for conv2
+    const int tid = threadIdx.x;
+    const float* tile = tiles + (size_t)blockIdx.x * 1024;
+
+    for (int i = tid; i < 33 * 33; i += 256) {
+        const int y = i / 33, x = i - y * 33;
+        t0[i] = (y == 0 || x == 0) ? 0.f : tile[(y - 1) * 32 + (x - 1)];
+    }
+    for (int i = tid; i < 16 * 17 * 17; i += 256) {
+        const int r = i % (17 * 17);
+        if (r < 17 || r % 17 == 0) a1[i] = 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * 256; i += 256) {
+        const int c = i >> 8, y = (i >> 4) & 15, x = i & 15;
+        float s = p.c1b[c];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) s = __builtin_fmaf(t0[(2 * y + ky) * 33 + 2 * x + kx], p.c1w[c * 9 + ky * 3 + kx], s);
+        a1[c * 289 + (y + 1) * 17 + (x + 1)] = leaky02(s);
+    }
+    __syncthreads();
+    // conv2: thread = (output channel, output row), 8 outputs along x in registers
+    const int o = tid & 31, y = tid >> 5;
+    float s[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) s[x] = p.c2b[o];
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float w = p.c2w[(c * 9 + ky * 3 + kx) * 32 + o];
+                const float* row = &a1[c * 289 + (2 * y + ky) * 17 + kx];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) s[x] = __builtin_fmaf(row[2 * x], w, s[x]);
+            }
+    float* dst = feat + (size_t)blockIdx.x * 2048 + o * 64 + y * 8;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 lo = {leaky02(s[0]), leaky02(s[1]), leaky02(s[2]), leaky02(s[3])};
+    f4 hi = {leaky02(s[4]), leaky02(s[5]), leaky02(s[6]), leaky02(s[7])};
+    *reinterpret_cast<f4*>(dst) = lo;
+    *reinterpret_cast<f4*>(dst + 4) = hi;
+}
+
 // ---- modulator ----------------------------------------------------------------------------------
 constexpr int MOD_ROWS = 8;  // patches per workgroup
 
@@ -158,8 +210,10 @@ __global__ __launch_bounds__(256) void modulator_layer_kernel(ModulatorLayerPara
 }
 
 
-// ---- modulator layer on the matrix cores ---------------------------------------------------------
-// Same contract as modulator_layer_kernel, for H, Z, Kh all multiples of 16.  One workgroup = one
+// ---- Linear layer over the batch on the matrix cores ---------------------------------------------
+// out[b, f] = act(bias[f] + sum_k in[b, k] * w[f, k]),  in = [hprev[b] ; z[b]]  (hprev may be absent):
+// the modulator layers (act = ReLU), and with Kh = 0 the encoder's conv3 (in = conv2 features, H = 64,
+// Z = 2048, LeakyReLU) and Linear(64, latent) (identity).  H, Z, Kh multiples of 16.  One workgroup = one
 // 16 x 16 output tile (16 patches x 16 features); its 4 waves split K four ways and each runs a chain
 // of v_mfma_f32_16x16x4_f32 (exact fp32) on float4 fragments read straight from the row-major
 // operands: lane l holds in[row l&15][k0 + 4(l>>4) + j] and W[feature l&15][k0 + 4(l>>4) + j], j = 0..3,
@@ -173,7 +227,9 @@ struct ModulatorMfmaParams {
     const float* z;      // (B, Z)
     float* out;          // (B, H)
     int B, H, Z, Kh;
+    int act;             // LIN_ACT_*
 };
+enum { LIN_ACT_RELU = 0, LIN_ACT_LEAKY02 = 1, LIN_ACT_NONE = 2 };
 
 __global__ __launch_bounds__(256) void modulator_layer_mfma_kernel(ModulatorMfmaParams p) {
     __shared__ float red[4][16][17];
@@ -189,8 +245,26 @@ __global__ __launch_bounds__(256) void modulator_layer_mfma_kernel(ModulatorMfma
     const float* hrow = p.hprev ? p.hprev + (size_t)row * p.H + 4 * kq : nullptr;
     const float* zrow = p.z + (size_t)row * p.Z + 4 * kq;
     mod_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int blk = b_lo; blk < b_hi; ++blk) {
+    // batches of 8 k-blocks: all 16 fragment loads of a batch are issued before its 32 MFMAs, so the wave
+    // pays one memory round trip per 128 k instead of one per 16
+    int blk = b_lo;
+    for (; blk + 8 <= b_hi; blk += 8) {
+        mod_f32x4 a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k0 = (blk + j) * 16;
+            a[j] = *reinterpret_cast<const mod_f32x4*>(k0 < p.Kh ? hrow + k0 : zrow + (k0 - p.Kh));
+            b[j] = *reinterpret_cast<const mod_f32x4*>(wrow + k0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], b[j][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], b[j][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], b[j][2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], b[j][3], acc1, 0, 0, 0);
+        }
+    }
+    for (; blk < b_hi; ++blk) {
         const int k0 = blk * 16;
         const mod_f32x4 a = *reinterpret_cast<const mod_f32x4*>(k0 < p.Kh ? hrow + k0 : zrow + (k0 - p.Kh));
         const mod_f32x4 b = *reinterpret_cast<const mod_f32x4*>(wrow + k0);
@@ -206,7 +280,8 @@ __global__ __launch_bounds__(256) void modulator_layer_mfma_kernel(ModulatorMfma
     const int rr = tid >> 4, cc = tid & 15;
     if (r0 + rr < p.B) {
         const float s = red[0][rr][cc] + red[1][rr][cc] + red[2][rr][cc] + red[3][rr][cc] + p.bias[f0 + cc];
-        p.out[(size_t)(r0 + rr) * p.H + f0 + cc] = s > 0.f ? s : 0.f;
+        const float neg = p.act == LIN_ACT_RELU ? 0.f : (p.act == LIN_ACT_LEAKY02 ? 0.2f * s : s);
+        p.out[(size_t)(r0 + rr) * p.H + f0 + cc] = s > 0.f ? s : neg;
     }
 }
 

@@ -59,7 +59,7 @@ struct msiren_ctx {
     // overlaps the encoder / modulator / trunk start of the next call.
     struct StreamCtx {
         hipStream_t s = nullptr;
-        DevBuf mods, modpad, latent, patches, keep, rec, queue;
+        DevBuf mods, modpad, latent, patches, keep, rec, queue, feat;
         unsigned queue_base = 0;  // value of the pass counter when the next launch starts
     } sc[2];
     int cur = 0, nstreams = 1;
@@ -84,7 +84,7 @@ struct msiren_ctx {
     // modulator: transposed weights so that consecutive threads read consecutive outputs
     float *d_modw = nullptr, *d_modb = nullptr, *d_modw_rm = nullptr;  // transposed / as stored (row-major)
     // encoder
-    float *d_encw = nullptr;
+    float *d_encw = nullptr, *d_c3w_rm = nullptr, *d_fcw_rm = nullptr;  // the latter two point into d_encw
     msiren::EncoderParams enc{};
     float* d_foldw = nullptr;  // (S,S) overlap-add weights
     // workspaces
@@ -465,6 +465,8 @@ int pack_encoder(msiren_ctx* h) {
         for (int k = 0; k < 64; ++k) fct[(size_t)k * Z + o] = (*t[6])[(size_t)o * 64 + k];
     size_t o_fcw = push(fct);
     size_t o_fcb = push(*t[7]);
+    size_t o_c3rm = push(*t[4]);  // (64, 2048) and (Z, 64) as stored: operands of the batched MFMA GEMMs
+    size_t o_fcrm = push(*t[6]);
     int rc;
     if ((rc = upload(&h->d_encw, blob))) return rc;
     ep.c1w = h->d_encw + o_c1w;
@@ -477,6 +479,8 @@ int pack_encoder(msiren_ctx* h) {
     ep.fcb = h->d_encw + o_fcb;
     ep.Z = Z;
     h->enc = ep;
+    h->d_c3w_rm = h->d_encw + o_c3rm;
+    h->d_fcw_rm = h->d_encw + o_fcrm;
     return 0;
 }
 
@@ -739,6 +743,7 @@ int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_d
         mp.H = h->H;
         mp.Z = h->Z;
         mp.Kh = Kh;
+        mp.act = msiren::LIN_ACT_RELU;
         dim3 grid((unsigned)((B + 15) / 16), (unsigned)(h->H / 16));
         hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, grid, dim3(256), 0, h->sc[h->cur].s, mp);
         HIPCHK(hipGetLastError());
@@ -770,7 +775,39 @@ int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_d
 int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_dev) {
     if (B == 0) return 0;
     if (!h->have_encoder) return fail(MSIREN_E_STATE, "encoder.* weights were not loaded");
-    hipLaunchKernelGGL(msiren::encoder_kernel, dim3((unsigned)B), dim3(256), 0, h->sc[h->cur].s, h->enc, tiles_dev, z_dev);
+    hipStream_t s = h->sc[h->cur].s;
+    if (h->Z % 16 != 0) {  // fused per-tile VALU kernel
+        hipLaunchKernelGGL(msiren::encoder_kernel, dim3((unsigned)B), dim3(256), 0, s, h->enc, tiles_dev, z_dev);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    // conv1+conv2 per tile, then conv3 == Linear(2048, 64) and Linear(64, Z) as GEMMs over the batch
+    auto& c = h->sc[h->cur];
+    int rc = ensure(h, c.feat, (size_t)B * (2048 + 64) * sizeof(float));
+    if (rc) return rc;
+    float* feat = (float*)c.feat.p;
+    float* a3 = feat + (size_t)B * 2048;
+    hipLaunchKernelGGL(msiren::encoder_conv_kernel, dim3((unsigned)B), dim3(256), 0, s, h->enc, tiles_dev, feat);
+    HIPCHK(hipGetLastError());
+    msiren::ModulatorMfmaParams mp{};
+    mp.w = h->d_c3w_rm;
+    mp.bias = h->enc.c3b;
+    mp.z = feat;
+    mp.out = a3;
+    mp.B = (int)B;
+    mp.H = 64;
+    mp.Z = 2048;
+    mp.act = msiren::LIN_ACT_LEAKY02;
+    hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, dim3((unsigned)((B + 15) / 16), 4), dim3(256), 0, s, mp);
+    HIPCHK(hipGetLastError());
+    mp.w = h->d_fcw_rm;
+    mp.bias = h->enc.fcb;
+    mp.z = a3;
+    mp.out = z_dev;
+    mp.H = h->Z;
+    mp.Z = 64;
+    mp.act = msiren::LIN_ACT_NONE;
+    hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, dim3((unsigned)((B + 15) / 16), (unsigned)(h->Z / 16)), dim3(256), 0, s, mp);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -890,7 +927,7 @@ int msiren_destroy(msiren_handle h) {
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
                       &h->sc[0].patches, &h->sc[0].keep, &h->sc[0].rec, &h->sc[1].mods, &h->sc[1].modpad, &h->sc[1].latent,
-                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec, &h->sc[0].queue, &h->sc[1].queue};
+                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec, &h->sc[0].queue, &h->sc[1].queue, &h->sc[0].feat, &h->sc[1].feat};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& pr : h->prof_events) {
