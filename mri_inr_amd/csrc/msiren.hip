@@ -776,7 +776,8 @@ int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_de
     if (B == 0) return 0;
     if (!h->have_encoder) return fail(MSIREN_E_STATE, "encoder.* weights were not loaded");
     hipStream_t s = h->sc[h->cur].s;
-    if (h->Z % 16 != 0) {  // fused per-tile VALU kernel
+    // small batches are launch-latency bound: one fused per-tile kernel instead of three launches
+    if (h->Z % 16 != 0 || B < 48) {
         hipLaunchKernelGGL(msiren::encoder_kernel, dim3((unsigned)B), dim3(256), 0, s, h->enc, tiles_dev, z_dev);
         HIPCHK(hipGetLastError());
         return 0;
