@@ -486,3 +486,42 @@ def test_rccl_broadcast_then_forward_single_rank():
     r = subprocess.run([sys.executable, "-c", script], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "NERR" in r.stdout
+
+
+def test_integration_md_ctypes_stub_runs_as_written():
+    """INTEGRATION.md §2 is the binding a maintainer would paste: execute that code block verbatim in a fresh
+    interpreter (no torch, no mri_inr_amd package -- only ctypes + numpy + libmsiren.so) and check its output."""
+    import re
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"## 2\..*?```python\n(.*?)```", doc, re.S).group(1)
+    assert "msiren_forward_tiles" in block and "msiren_create" in block
+    prologue = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("syn", %r)   # synthetic weights only (pure numpy)
+        syn = importlib.util.module_from_spec(spec); spec.loader.exec_module(syn)
+        class _T:                                   # the two tensor methods the stub uses
+            def __init__(self, a): self.a = a
+            def cpu(self): return self
+            def numpy(self): return self.a
+        sd = syn.make_state_dict(seed=7, trained_like=True)
+        state_dict = {k: _T(v) for k, v in sd.items()}
+        tiles = np.random.default_rng(5).random((9, 32, 32), dtype=np.float32)
+    """) % (root, os.path.join(root, "mri_inr_amd", "synthetic.py"))
+    epilogue = textwrap.dedent("""
+        assert "torch" not in sys.modules and "mri_inr_amd" not in sys.modules
+        from oracle import siren_oracle as orc
+        ref = orc.modulated_siren_forward(sd, tiles, num_layers=5, dtype=np.float64)
+        err = float(np.abs(out - ref).max() / np.abs(ref).max())
+        print("NERR", err)
+        sys.exit(0 if err < 1e-4 else 1)
+    """)
+    r = subprocess.run([sys.executable, "-c", prologue + block + epilogue], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "NERR" in r.stdout
