@@ -63,6 +63,7 @@ struct msiren_ctx {
         unsigned queue_base = 0;  // value of the pass counter when the next launch starts
     } sc[2];
     int cur = 0, nstreams = 1;
+    bool overlap = false;  // a host-pointer call is pipelining itself over both streams
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, std::vector<float>> tensors;  // state_dict, host copies
     std::map<std::string, size_t> expected;             // key -> element count
@@ -610,7 +611,7 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     }
     // R = 3 leaves ~35 KB of LDS per CU free, enough for an encoder / modulator workgroup of the NEXT
     // call (other stream) to run beside the persistent trunk workgroup; R = 4 fills the CU.
-    int ring = h->nstreams > 1 ? 3 : 4;
+    int ring = (h->nstreams > 1 || h->overlap) ? 3 : 4;
     if (const char* e = std::getenv("MSIREN_F16_RING")) ring = std::atoi(e);
     if (ring >= 4 && msiren::F16Lds<4>::total(h->L) <= 160 * 1024) return launch_trunk_f16x3_r<4>(h, p, grid);
     return launch_trunk_f16x3_r<3>(h, p, grid);
@@ -1035,11 +1036,37 @@ int msiren_forward_tiles(msiren_handle h, const float* tiles_host, int64_t B, fl
     if (B == 0) return 0;
     const size_t nt = (size_t)B * h->O * h->O * sizeof(float), no = (size_t)B * h->P * sizeof(float);
     if ((rc = ensure(h, h->ws_tiles, nt)) || (rc = ensure(h, h->ws_out, no))) return rc;
-    HIPCHK(hipMemcpyAsync(h->ws_tiles.p, tiles_host, nt, hipMemcpyHostToDevice, h->sc[h->cur].s));
-    if ((rc = forward_tiles_dev(h, (const float*)h->ws_tiles.p, B, (float*)h->ws_out.p))) return rc;
-    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->sc[h->cur].s));
-    HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
-    return 0;
+    // A synchronous call cannot be overlapped by its caller, so a large one pipelines its copies itself: the
+    // batch is cut in two halves on the two streams -- the second half's upload runs beside the first half's
+    // kernels, the first half's download beside the second half's trunk.  (More than two chunks do not help:
+    // a pageable copy waits for its stream to drain.)  Patches are independent: the cut does not change results.
+    int nchunks = B >= 256 ? 2 : 1;
+    if (const char* e = std::getenv("MSIREN_HOST_CHUNKS")) nchunks = std::max(1, std::min(std::atoi(e), 16));  // experiment knob
+    nchunks = (int)std::min<int64_t>(nchunks, B);
+    const int cur0 = h->cur;
+    const size_t tile_elems = (size_t)h->O * h->O;
+    h->overlap = nchunks > 1;
+    for (int k = 0; k < nchunks && !rc; ++k) {
+        const int64_t lo = B * k / nchunks, n = B * (k + 1) / nchunks - lo;
+        h->cur = nchunks > 1 ? (k & 1) : cur0;
+        float* d_t = (float*)h->ws_tiles.p + (size_t)lo * tile_elems;
+        hipError_t e = hipMemcpyAsync(d_t, tiles_host + (size_t)lo * tile_elems, (size_t)n * tile_elems * sizeof(float),
+                                      hipMemcpyHostToDevice, h->sc[h->cur].s);
+        if (e != hipSuccess) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(H2D): %s", hipGetErrorString(e));
+        if (!rc) rc = forward_tiles_dev(h, d_t, n, (float*)h->ws_out.p + (size_t)lo * h->P);
+    }
+    // downloads are enqueued after ALL launches: a pageable D2H blocks the host until its chunk is done
+    for (int k = 0; k < nchunks && !rc; ++k) {
+        const int64_t lo = B * k / nchunks, n = B * (k + 1) / nchunks - lo;
+        h->cur = nchunks > 1 ? (k & 1) : cur0;
+        hipError_t e = hipMemcpyAsync(out_host + (size_t)lo * h->P, (float*)h->ws_out.p + (size_t)lo * h->P,
+                                      (size_t)n * h->P * sizeof(float), hipMemcpyDeviceToHost, h->sc[h->cur].s);
+        if (e != hipSuccess) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(D2H): %s", hipGetErrorString(e));
+    }
+    h->overlap = false;
+    h->cur = cur0;
+    const int rs = sync_all(h);
+    return rc ? rc : rs;
 }
 
 int msiren_recon_shape(msiren_handle h, int32_t height, int32_t width, int32_t* nv, int32_t* nh) {

@@ -311,6 +311,14 @@ def test_two_stream_pipelining_is_bit_identical():
             assert np.array_equal(m.reconstruct(img), ref_img)
             assert np.array_equal(m(tiles[0]), ref[0])
         _lib.check(m._lib.msiren_set_streams(m._h, 1))
+        # a large synchronous host call cuts itself in two halves over the two streams (copy overlap):
+        # same bits as the whole batch through the device entry point
+        big = np.random.default_rng(9).random((401, 32, 32), dtype=np.float32)
+        d_big, d_res = m.device_array(big.shape).copy_from(big), m.device_array((401, 24, 24))
+        _lib.check(m._lib.msiren_forward_tiles_dev(m._h, d_big.ptr, 401, d_res.ptr))
+        m.sync()
+        for _ in range(2):
+            assert np.array_equal(m(big), d_res.numpy())
 
 
 @pytest.mark.parametrize("H,L,Z,act", [(512, 10, 128, "sine"), (256, 4, 64, "morlet")])
