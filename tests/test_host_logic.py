@@ -102,3 +102,34 @@ def test_model_object_protocol_without_gpu():
     assert not any(k.startswith("encoder.") for k in m2.state_dict())
     with pytest.raises(AttributeError):
         m2(np.zeros((1, 32, 32), np.float32))
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The bench line recorded on the MI355X (profiles/r1/13_final/bench_default.json) carries every key of the
+    driver's contract, the roofline and cpu_baseline objects, and self-consistent arithmetic."""
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = json.loads(open(os.path.join(root, "profiles", "r1", "13_final", "bench_default.json")).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["unit"] == "Mpixel/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None and line["data"] == "synthetic" and "workload" in line["config"]
+    assert "model" not in line["config"]
+    # value = pixels of all ranks per step / time per step
+    px = line["n_gpus"] * line["config"]["slices_per_gpu_per_step"] * 320 * 320
+    assert abs(line["value"] - px / (line["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * line["value"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    # algorithmic FLOPs per launch = 525 824 per coordinate x 576 coordinates x 400 tiles (SURVEY.md §8d)
+    assert r["flops_per_launch"] == 525824 * 576 * 400
+    c = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["unit"] == line["unit"] and c["cores"] >= 1
