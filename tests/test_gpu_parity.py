@@ -533,3 +533,44 @@ def test_integration_md_ctypes_stub_runs_as_written():
     r = subprocess.run([sys.executable, "-c", prologue + block + epilogue], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "NERR" in r.stdout
+
+
+def test_tiling_kernels_ragged_sizes_vs_oracle():
+    """image_to_patches / weighted fold / whole-slice pipeline for image sizes that are not multiples of the
+    stride, several slices per call, down to the smallest size reflect padding accepts -- against the oracle
+    (itself pinned to the reference's tiling.py by tests/golden/tiling.npz).  Byte moving is bit-exact."""
+    import ctypes as C
+
+    from mri_inr_amd import _lib
+
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = make_model(sd)
+    rng = np.random.default_rng(21)
+    for n, hh, ww in ((1, 16, 25), (2, 33, 47), (3, 64, 48), (1, 100, 321), (2, 319, 35), (1, 24, 400)):
+        imgs = rng.random((n, hh, ww), dtype=np.float32)
+        imgs[:, : hh // 3, : ww // 3] = 0.0  # some black tiles
+        nv, nh = C.c_int32(), C.c_int32()
+        _lib.check(m._lib.msiren_recon_shape(m._h, hh, ww, C.byref(nv), C.byref(nh)))
+        ref_p, info = zip(*(orc.image_to_patches(im, 32, 16) for im in imgs))
+        assert (nv.value, nh.value) == tuple(np.ravel(info[0]))
+        per = nv.value * nh.value
+        d_img = m.device_array(imgs.shape).copy_from(imgs)
+        d_p = m.device_array((n * per, 32, 32))
+        _lib.check(m._lib.msiren_image_to_patches_dev(m._h, d_img.ptr, n, hh, ww, d_p.ptr))
+        m.sync()
+        assert np.array_equal(d_p.numpy(), np.concatenate(ref_p, 0)), (n, hh, ww)
+        rec = rng.random((n * per, 24, 24), dtype=np.float32)
+        d_r = m.device_array(rec.shape).copy_from(rec)
+        d_o = m.device_array((n, nv.value * 16, nh.value * 16))
+        _lib.check(m._lib.msiren_weighted_fold_dev(m._h, d_r.ptr, n, nv.value, nh.value, d_o.ptr))
+        m.sync()
+        ref_o = np.stack([orc.patches_to_image_weighted_average(rec[k * per:(k + 1) * per], info[k], 24, 16) for k in range(n)])
+        assert nerr(d_o.numpy(), ref_o) < 2e-6, (n, hh, ww)
+        # the whole pipeline, black tiles included
+        got = m.reconstruct(imgs)
+        ref = np.stack([orc.reconstruct_slice(sd, im, num_layers=5, dtype=np.float64) for im in imgs])
+        assert got.shape == ref.shape and nerr(got, ref) < 1e-4, (n, hh, ww, nerr(got, ref))
+    # too small for reflect padding (F.pad raises in the reference): refused, not mis-tiled
+    for bad in ((8, 40), (17, 17)):
+        with pytest.raises((ValueError, RuntimeError)):
+            m.reconstruct(np.ones(bad, np.float32))
