@@ -197,6 +197,10 @@ def image_to_patches(img, outer: int, inner: int):
     pad = (outer - inner) // 2
     vpad = (inner - Hh % inner) % inner
     hpad = (inner - Ww % inner) % inner
+    # torch's reflect padding (F.pad in tiling.py:40) raises unless every pad is smaller than the dimension;
+    # numpy would silently reflect more than once
+    if pad + vpad >= Hh or pad + hpad >= Ww:
+        raise ValueError(f"image {Hh}x{Ww} is too small for reflect padding of {pad + vpad}/{pad + hpad}")
     padded = np.pad(img, ((pad, pad + vpad), (pad, pad + hpad)), mode="reflect")
     nV = (Hh + vpad) // inner
     nH = (Ww + hpad) // inner

@@ -132,3 +132,15 @@ def test_torch_twin_matches_reference_fixture(act):
     tiles = np.random.default_rng(42).random((8, 32, 32), dtype=np.float32)
     out = tw.forward_tiles(tw.to_tensors(sd), torch.from_numpy(tiles), num_layers=5, activation=act).numpy()
     assert nerr(out, g["out"]) < 5e-5
+
+
+def test_tiling_refuses_images_too_small_for_reflect_padding():
+    """F.pad(mode="reflect") in the reference (tiling.py:40) raises when a pad reaches the dimension; the
+    restatement must not silently reflect twice."""
+    import pytest
+
+    for bad in ((8, 40), (17, 17), (40, 20)):
+        with pytest.raises(ValueError):
+            orc.image_to_patches(np.ones(bad, np.float32), 32, 16)
+    patches, info = orc.image_to_patches(np.ones((16, 25), np.float32), 32, 16)
+    assert patches.shape == (2, 32, 32) and tuple(info) == (1, 2)
