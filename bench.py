@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--pipeline", default="forward", choices=["forward", "reconstruct"],
                     help="forward = ModulatedSiren.forward on resident tiles (the metric's timed region); "
                          "reconstruct = slice -> tiles -> black filter -> forward -> weighted fold -> slice, all on the device")
+    ap.add_argument("--brain-mask", action="store_true",
+                    help="elliptical brain-like mask on the synthetic slices (43 %% of the tiles become black; only "
+                         "--pipeline reconstruct skips them, as the reference's black-patch filter does)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--check", action="store_true", help="also verify one batch against the oracle")
@@ -165,7 +168,7 @@ def main():
 
     # ---- synthetic input: slice k = default_rng(1000+k).random((320,320)), tiled 32/16 on the device ----
     n_sl = args.slices
-    imgs = np.stack([syn.make_slice(rank * n_sl + k) for k in range(n_sl)])
+    imgs = np.stack([syn.make_slice(rank * n_sl + k, brain_mask=args.brain_mask) for k in range(n_sl)])
     B = n_sl * 400
     d_img = model.device_array(imgs.shape).copy_from(imgs)
     d_tiles = model.device_array((B, 32, 32))
@@ -261,7 +264,7 @@ def main():
                         "tiles and outputs resident in HBM",
             "slices_per_gpu_per_step": n_sl, "patches_per_step_per_gpu": B, "coords_per_patch": 576,
             "dim_hidden": H, "num_layers": L, "latent_dim": Z, "residual": deep, "activation": args.activation, "precision": args.precision, "streams": args.streams,
-            "pipeline": args.pipeline,
+            "pipeline": args.pipeline, "brain_mask": bool(args.brain_mask),
             "parallelism": f"patch-shard x{world}",
         },
         "roofline": {

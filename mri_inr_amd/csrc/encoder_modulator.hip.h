@@ -22,6 +22,7 @@ struct EncoderParams {
     const float* fcw;  // (64, Z) transposed   Linear(64, Z)
     const float* fcb;  // (Z)
     int Z;
+    const int* plan;   // optional (compact_flags_kernel): workgroup j handles tile plan[2 + j], j < plan[0]
 };
 
 __device__ __forceinline__ float leaky02(float x) { return x >= 0.f ? x : 0.2f * x; }
@@ -36,7 +37,8 @@ __global__ __launch_bounds__(256, 5) void encoder_kernel(EncoderParams p, const 
     __shared__ float red[4 * 64];
     __shared__ float a3[64];
     const int tid = threadIdx.x;
-    const float* tile = tiles + (size_t)blockIdx.x * 1024;
+    if (p.plan && (int)blockIdx.x >= p.plan[0]) return;  // workgroup-uniform
+    const float* tile = tiles + (size_t)(p.plan ? p.plan[2 + blockIdx.x] : (int)blockIdx.x) * 1024;
 
     for (int i = tid; i < 33 * 33; i += 256) {
         const int y = i / 33, x = i - y * 33;
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(256, 5) void encoder_conv_kernel(EncoderParams p, c
     __shared__ float t0[33 * 33];       // input with a zero row/column in front (padding = 1)
     __shared__ float a1[16 * 17 * 17];  // conv1 output, same front padding for conv2
     const int tid = threadIdx.x;
-    const float* tile = tiles + (size_t)blockIdx.x * 1024;
+    if (p.plan && (int)blockIdx.x >= p.plan[0]) return;  // workgroup-uniform
+    const float* tile = tiles + (size_t)(p.plan ? p.plan[2 + blockIdx.x] : (int)blockIdx.x) * 1024;
 
     for (int i = tid; i < 33 * 33; i += 256) {
         const int y = i / 33, x = i - y * 33;
@@ -164,6 +167,7 @@ struct ModulatorLayerParams {
     const float* z;      // (B, Z)
     float* out;          // (B, H)
     int B, H, Z, Kh;
+    const int* count;    // optional: number of rows to process, on the device (<= B)
 };
 
 // out[b, f] = relu(bias[f] + sum_k in[b, k] * wt[k, f]),  in = [hprev[b] ; z[b]].
@@ -174,11 +178,13 @@ __global__ __launch_bounds__(256) void modulator_layer_kernel(ModulatorLayerPara
     const int tid = threadIdx.x;
     const int K = p.Kh + p.Z;
     const int b0 = blockIdx.x * MOD_ROWS;
+    const int nrows = p.count ? *p.count : p.B;
+    if (b0 >= nrows) return;  // workgroup-uniform
     for (int i = tid; i < MOD_ROWS * K; i += 256) {
         const int r = i / K, k = i - r * K;
         const int b = b0 + r;
         float v = 0.f;
-        if (b < p.B) v = k < p.Kh ? p.hprev[(size_t)b * p.H + k] : p.z[(size_t)b * p.Z + (k - p.Kh)];
+        if (b < nrows) v = k < p.Kh ? p.hprev[(size_t)b * p.H + k] : p.z[(size_t)b * p.Z + (k - p.Kh)];
         in[i] = v;
     }
     __syncthreads();
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256) void modulator_layer_kernel(ModulatorLayerPara
     for (int i = tid; i < MOD_ROWS * 64; i += 256) {
         const int r = i >> 6, ff = i & 63;
         const int b = b0 + r, fo = blockIdx.y * 64 + ff;
-        if (b < p.B && fo < p.H) {
+        if (b < nrows && fo < p.H) {
             const float s = red[0][r][ff] + red[1][r][ff] + red[2][r][ff] + red[3][r][ff] + p.bias[fo];
             p.out[(size_t)b * p.H + fo] = s > 0.f ? s : 0.f;
         }
@@ -228,6 +234,7 @@ struct ModulatorMfmaParams {
     float* out;          // (B, H)
     int B, H, Z, Kh;
     int act;             // LIN_ACT_*
+    const int* count;    // optional: number of rows to process, on the device (<= B)
 };
 enum { LIN_ACT_RELU = 0, LIN_ACT_LEAKY02 = 1, LIN_ACT_NONE = 2 };
 
@@ -235,7 +242,9 @@ __global__ __launch_bounds__(256) void modulator_layer_mfma_kernel(ModulatorMfma
     __shared__ float red[4][16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * 16, f0 = blockIdx.y * 16;
-    const int row = min(r0 + (lane & 15), p.B - 1);
+    const int nrows = p.count ? *p.count : p.B;
+    if (r0 >= nrows) return;  // workgroup-uniform
+    const int row = min(r0 + (lane & 15), nrows - 1);
     const int f = f0 + (lane & 15);
     const int kq = lane >> 4;
     const int K = p.Kh + p.Z;
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(256) void modulator_layer_mfma_kernel(ModulatorMfma
     for (int r = 0; r < 4; ++r) red[wave][4 * kq + r][lane & 15] = acc0[r] + acc1[r];
     __syncthreads();
     const int rr = tid >> 4, cc = tid & 15;
-    if (r0 + rr < p.B) {
+    if (r0 + rr < nrows) {
         const float s = red[0][rr][cc] + red[1][rr][cc] + red[2][rr][cc] + red[3][rr][cc] + p.bias[f0 + cc];
         const float neg = p.act == LIN_ACT_RELU ? 0.f : (p.act == LIN_ACT_LEAKY02 ? 0.2f * s : s);
         p.out[(size_t)(r0 + rr) * p.H + f0 + cc] = s > 0.f ? s : neg;

@@ -59,11 +59,12 @@ struct msiren_ctx {
     // overlaps the encoder / modulator / trunk start of the next call.
     struct StreamCtx {
         hipStream_t s = nullptr;
-        DevBuf mods, modpad, latent, patches, keep, rec, queue, feat;
+        DevBuf mods, modpad, latent, patches, keep, rec, queue, feat, plan;
         unsigned queue_base = 0;  // value of the pass counter when the next launch starts
     } sc[2];
     int cur = 0, nstreams = 1;
     bool overlap = false;  // a host-pointer call is pipelining itself over both streams
+    const int* plan = nullptr;  // device-side list of non-black patches in effect (slice pipeline only)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, std::vector<float>> tensors;  // state_dict, host copies
     std::map<std::string, size_t> expected;             // key -> element count
@@ -542,6 +543,7 @@ msiren::TrunkParams make_trunk_params(msiren_ctx* h, const float* mods, int stri
     p.mod_stride = stride;
     p.chunks = (h->P + 63) / 64;
     p.stamps = nullptr;
+    p.plan = h->plan;
     return p;
 }
 
@@ -559,6 +561,15 @@ int queue_for_launch(msiren_ctx* h, int64_t npasses, int** counter, unsigned* ba
     *counter = (int*)c.queue.p;
     *base = c.queue_base;
     c.queue_base += (unsigned)npasses;
+    return 0;
+}
+
+// After a launch whose number of passes only the device knows (black patches skipped): reset the counter.
+int queue_reset_after_plan_launch(msiren_ctx* h) {
+    auto& c = h->sc[h->cur];
+    if (!c.queue.p) return 0;
+    HIPCHK(hipMemsetAsync(c.queue.p, 0, 4, c.s));
+    c.queue_base = 0;
     return 0;
 }
 
@@ -603,6 +614,7 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     const int64_t units = B * p.units_per_patch;
     if (units > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     p.total_units = (int)units;
+    p.plan = h->plan;
     int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
     if (const char* e = std::getenv("MSIREN_GRID")) grid = std::max(1, std::min(grid, std::atoi(e)));  // experiment knob
     {   // pass queue: workgroup g starts with pass g, further passes come from this counter
@@ -638,6 +650,7 @@ int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_
     const int64_t units = B * p.units_per_patch;
     if (units > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     p.total_units = (int)units;
+    p.plan = h->plan;
     const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
     int rc = queue_for_launch(h, (units + 3) / 4, &p.pass_counter, &p.pass_base);
     if (rc) return rc;
@@ -745,6 +758,7 @@ int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_d
         mp.Z = h->Z;
         mp.Kh = Kh;
         mp.act = msiren::LIN_ACT_RELU;
+        mp.count = h->plan;
         dim3 grid((unsigned)((B + 15) / 16), (unsigned)(h->H / 16));
         hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, grid, dim3(256), 0, h->sc[h->cur].s, mp);
         HIPCHK(hipGetLastError());
@@ -764,6 +778,7 @@ int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_d
         mp.H = h->H;
         mp.Z = h->Z;
         mp.Kh = Kh;
+        mp.count = h->plan;
         dim3 grid((unsigned)((B + msiren::MOD_ROWS - 1) / msiren::MOD_ROWS), (unsigned)((h->H + 63) / 64));
         const size_t lds = (size_t)msiren::MOD_ROWS * (Kh + h->Z) * sizeof(float);
         hipLaunchKernelGGL(msiren::modulator_layer_kernel, grid, dim3(256), lds, h->sc[h->cur].s, mp);
@@ -777,6 +792,7 @@ int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_de
     if (B == 0) return 0;
     if (!h->have_encoder) return fail(MSIREN_E_STATE, "encoder.* weights were not loaded");
     hipStream_t s = h->sc[h->cur].s;
+    h->enc.plan = h->plan;
     // small batches are launch-latency bound: one fused per-tile kernel instead of three launches
     if (h->Z % 16 != 0 || B < 48) {
         hipLaunchKernelGGL(msiren::encoder_kernel, dim3((unsigned)B), dim3(256), 0, s, h->enc, tiles_dev, z_dev);
@@ -800,6 +816,7 @@ int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_de
     mp.H = 64;
     mp.Z = 2048;
     mp.act = msiren::LIN_ACT_LEAKY02;
+    mp.count = h->plan;
     hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, dim3((unsigned)((B + 15) / 16), 4), dim3(256), 0, s, mp);
     HIPCHK(hipGetLastError());
     mp.w = h->d_fcw_rm;
@@ -929,7 +946,7 @@ int msiren_destroy(msiren_handle h) {
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
                       &h->sc[0].patches, &h->sc[0].keep, &h->sc[0].rec, &h->sc[1].mods, &h->sc[1].modpad, &h->sc[1].latent,
-                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec, &h->sc[0].queue, &h->sc[1].queue, &h->sc[0].feat, &h->sc[1].feat};
+                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec, &h->sc[0].queue, &h->sc[1].queue, &h->sc[0].feat, &h->sc[1].feat, &h->sc[0].plan, &h->sc[1].plan};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& pr : h->prof_events) {
@@ -1102,7 +1119,7 @@ int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev, int64_t n,
     if (n == 0) return 0;
     const int64_t total = n * nV * h->I * (int64_t)nH * h->I;
     hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->sc[h->cur].s,
-                       tiles_dev, h->d_foldw, recon_dev, nullptr, n, nV, nH, h->S, h->I, (h->S - h->I) / 2);
+                       tiles_dev, h->d_foldw, recon_dev, nullptr, nullptr, n, nV, nH, h->S, h->I, (h->S - h->I) / 2);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1125,17 +1142,27 @@ static int reconstruct_on_current_stream(msiren_handle h, const float* images_de
     int* black = (int*)h->sc[h->cur].keep.p;
     float* rec = (float*)h->sc[h->cur].rec.p;
     if ((rc = msiren_image_to_patches_dev(h, images_dev, n, height, width, patches))) return rc;
-    // The reference compacts the non-black tiles, runs the model, and scatters zeros back
-    // (tiling.py:244-303).  Patches are independent, so evaluating all of them in place and
-    // zeroing the black ones in the fold gives identical results without a device-side compaction.
-    hipLaunchKernelGGL(msiren::black_flags_kernel, dim3((unsigned)NP), dim3(256), 0, h->sc[h->cur].s, patches, black, h->O * h->O);
+    // The reference compacts the non-black tiles, runs the model on those only, and scatters zeros back
+    // (tiling.py:244-303).  Same here, on the device: black flags -> list of kept patches (the "plan") ->
+    // encoder / modulator / trunk over the kept patches only (their count stays on the device) -> the fold
+    // looks each patch up through the plan and lets black ones contribute zeros.
+    if ((rc = ensure(h, h->sc[h->cur].plan, (size_t)(2 + 2 * NP) * sizeof(int)))) return rc;
+    int* plan = (int*)h->sc[h->cur].plan.p;
+    hipStream_t st = h->sc[h->cur].s;
+    hipLaunchKernelGGL(msiren::black_flags_kernel, dim3((unsigned)NP), dim3(256), 0, st, patches, black, h->O * h->O);
     HIPCHK(hipGetLastError());
-    if ((rc = launch_encoder(h, patches, NP, (float*)h->sc[h->cur].latent.p))) return rc;
-    if ((rc = launch_modulator(h, (const float*)h->sc[h->cur].latent.p, NP, (float*)h->sc[h->cur].mods.p))) return rc;
-    if ((rc = launch_trunk(h, (const float*)h->sc[h->cur].mods.p, NP, rec))) return rc;
+    hipLaunchKernelGGL(msiren::compact_flags_kernel, dim3(1), dim3(256), 0, st, black, (int)NP, (h->P + 31) / 32, plan);
+    HIPCHK(hipGetLastError());
+    h->plan = plan;
+    rc = launch_encoder(h, patches, NP, (float*)h->sc[h->cur].latent.p);
+    if (!rc) rc = launch_modulator(h, (const float*)h->sc[h->cur].latent.p, NP, (float*)h->sc[h->cur].mods.p);
+    if (!rc) rc = launch_trunk(h, (const float*)h->sc[h->cur].mods.p, NP, rec);
+    h->plan = nullptr;
+    if (rc) return rc;
+    if ((rc = queue_reset_after_plan_launch(h))) return rc;
     const int64_t total = n * nV * h->I * (int64_t)nH * h->I;
-    hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->sc[h->cur].s,
-                       rec, h->d_foldw, recon_dev, black, n, nV, nH, h->S, h->I, (h->S - h->I) / 2);
+    hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       rec, h->d_foldw, recon_dev, black, plan + 2 + NP, n, nV, nH, h->S, h->I, (h->S - h->I) / 2);
     HIPCHK(hipGetLastError());
     return 0;
 }

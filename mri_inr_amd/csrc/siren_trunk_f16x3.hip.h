@@ -45,6 +45,7 @@ struct TrunkF16Params {
     float winv[16];           // per hidden layer: exact inverse of the power-of-two weight scale
     float bout, cg0, cg;
     int B, P, L, units_per_patch, total_units;
+    const int* plan;          // optional (compact_flags_kernel): the unit count is plan[1] (<= total_units)
     int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
     unsigned pass_base;        // value of *pass_counter when this launch starts (arithmetic is modulo 2^32)
     unsigned long long* stamps; // diagnostic instantiation only: [grid][8 passes][8] s_memtime + realtime
@@ -185,7 +186,9 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         MSIREN_DMA_PIECE(6);
         MSIREN_DMA_PIECE(7);
     };
-    if (cur_pass * 4 >= p.total_units) return;
+    // the kept patches only: known on the device (scalar: a vector register here costs the co-residency of §4.3)
+    const int total_units = __builtin_amdgcn_readfirstlane(p.plan ? p.plan[1] : p.total_units);
+    if (cur_pass * 4 >= total_units) return;
 #pragma unroll
     for (int s = 0; s < R - 1; ++s) dma_next();
 
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         wf_[0][3] = r0[3 * 64];
     }
 
-    for (int pass = 0; cur_pass * 4 < p.total_units; ++pass) {
+    for (int pass = 0; cur_pass * 4 < total_units; ++pass) {
         auto stamp = [&](int i) {
             if constexpr (DBG) {
                 const unsigned long long t = i == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
@@ -418,8 +421,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         int dbg_tile = 0;
         (void)dbg_tile;
         int unit = cur_pass * 4 + wave;
-        const bool active = unit < p.total_units;
-        unit = active ? unit : p.total_units - 1;
+        const bool active = unit < total_units;
+        unit = active ? unit : total_units - 1;
         const int b = unit / p.units_per_patch;
         const int cu = unit - b * p.units_per_patch;
         int pc = cu * 32 + c32;

@@ -43,6 +43,7 @@ struct TrunkParams {
     float cg0, cg;       // Morlet Gaussian constants for layer 0 / hidden layers
     int B, P, L, mod_stride, chunks;
     unsigned long long* stamps;  // diagnostic build only: [grid][32] s_memtime stamps
+    const int* plan;     // optional (compact_flags_kernel): only patches b < plan[0] are evaluated
 };
 
 // sin(2*pi*r) with the hardware sine, whose argument is in revolutions.  On gfx950 v_sin_f32 performs
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
     const int c32 = lane & 31;
     const int b = blockIdx.x / p.chunks;
     const int ch = blockIdx.x - b * p.chunks;
+    if (p.plan && b >= p.plan[0]) return;  // workgroup-uniform, before any barrier
     const int L = p.L;
     int nstamp = 0;
     auto stamp = [&]() {

@@ -40,6 +40,7 @@ struct TrunkX1Params {
     float winv[64];           // per hidden layer: exact inverse of the power-of-two weight scale
     float bout, cg0, cg;
     int B, P, L, units_per_patch, total_units;
+    const int* plan;          // optional (compact_flags_kernel): the unit count is plan[1] (<= total_units)
     int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
     unsigned pass_base;
 };
@@ -157,7 +158,9 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
         dma_id = dma_id + 1 == nchunks ? 0 : dma_id + 1;
         dma_buf = dma_buf + 1 == R ? 0 : dma_buf + 1;
     };
-    if (cur_pass * 4 >= p.total_units) return;
+    // the kept patches only: known on the device (scalar: a vector register here costs the co-residency of §4.3)
+    const int total_units = __builtin_amdgcn_readfirstlane(p.plan ? p.plan[1] : p.total_units);
+    if (cur_pass * 4 >= total_units) return;
 #pragma unroll
     for (int s = 0; s < R - 1; ++s) dma_next();
 
@@ -328,10 +331,10 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
         wf_[0][3] = r0[3 * 64];
     }
 
-    for (int pass = 0; cur_pass * 4 < p.total_units; ++pass) {
+    for (int pass = 0; cur_pass * 4 < total_units; ++pass) {
         int unit = cur_pass * 4 + wave;
-        const bool active = unit < p.total_units;
-        unit = active ? unit : p.total_units - 1;
+        const bool active = unit < total_units;
+        unit = active ? unit : total_units - 1;
         const int b = unit / p.units_per_patch;
         const int cu = unit - b * p.units_per_patch;
         int pc = cu * 32 + c32;

@@ -55,11 +55,53 @@ __global__ __launch_bounds__(256) void black_flags_kernel(const float* __restric
     }
 }
 
+// filter_and_remember_black_patches (tiling.py:244-271) as a device-side plan: the non-black patches in
+// order.  plan[0] = their number, plan[1] = plan[0] * units_per_patch (the trunk's unit count),
+// plan[2 + j] = index of the j-th kept patch, plan[2 + n + b] = position of patch b among the kept ones
+// (-1: black).  Encoder, modulator and trunk then work on the kept patches only -- like the reference,
+// which never evaluates the model on a black tile -- without the host learning the count.
+// One workgroup of 256 threads (one wave per SIMD, few registers: it has to fit beside a resident trunk
+// workgroup of the other stream); n is a few hundred per slice.
+__global__ __launch_bounds__(256) void compact_flags_kernel(const int* __restrict__ flags, int n, int units_per_patch, int* __restrict__ plan) {
+    __shared__ int wsum[4];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int b = base + tid;
+        const int keep = (b < n && flags[b] == 0) ? 1 : 0;
+        int incl = keep;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        const int j = before + incl - keep;
+        if (b < n) {
+            plan[2 + n + b] = keep ? j : -1;
+            if (keep) plan[2 + j] = b;
+        }
+        __syncthreads();
+        if (tid == 255) carry = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        plan[0] = carry;
+        plan[1] = carry * units_per_patch;
+    }
+}
+
 // patches_to_image_weighted_average (tiling.py:91-140): fold(tiles * w) / fold(w) with kernel S,
 // stride I, padding `pad`.  Black patches (flags[b] != 0) contribute zeros with their full weight,
 // as reintegrate_black_patches + fold do in the reference (tiling.py:287-301, :117-118).
+// `pos` (optional): tiles holds the kept patches only, patch b at row pos[b] (compact_flags_kernel).
 __global__ void weighted_fold_kernel(const float* __restrict__ tiles, const float* __restrict__ w, float* __restrict__ recon,
-                                     const int* __restrict__ flags, int64_t n, int nV, int nH, int S, int I, int pad) {
+                                     const int* __restrict__ flags, const int* __restrict__ pos, int64_t n, int nV, int nH, int S, int I, int pad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int OH = nV * I, OW = nH * I;
     if (i >= n * OH * (int64_t)OW) return;
@@ -79,7 +121,7 @@ __global__ void weighted_fold_kernel(const float* __restrict__ tiles, const floa
             const int64_t b = (s * nV + v) * nH + hh;
             const float ww = w[ty * S + tx];
             den += ww;
-            if (!flags || flags[b] == 0) num += tiles[(b * S + ty) * S + tx] * ww;
+            if (!flags || flags[b] == 0) num += tiles[((pos ? (int64_t)pos[b] : b) * S + ty) * S + tx] * ww;
         }
     recon[i] = num / den;
 }
