@@ -238,7 +238,11 @@ def main():
 
     px_per_step = world * n_sl * 320 * 320
     value = px_per_step * args.steps / elapsed / 1e6
-    flops_launch = model.flops_per_coord() * B * 576
+    # the slice pipeline skips black tiles (mean < 1e-10, tiling.py:184-198): only evaluated tiles count as work
+    evaluated = B
+    if d_recons is not None:
+        evaluated = int((d_tiles.numpy().reshape(B, -1).mean(axis=1, dtype=np.float32) >= np.float32(1e-10)).sum())
+    flops_launch = model.flops_per_coord() * evaluated * 576
     trunk_avg_s = trunk_ms.value / max(launches.value, 1) / 1e3
     achieved = flops_launch / trunk_avg_s / 1e12
 
@@ -262,7 +266,8 @@ def main():
             "workload": f"BASELINE configs[{4 if deep else 1}]{' (deep residual 10x512, own semantics)' if deep else ''}: {n_sl} x 320x320 slice per GPU per step -> {B} tiles 32x32 -> "
                         f"ModulatedSiren.forward (encoder+modulator+fused trunk, {args.activation}) -> {B}x24x24; "
                         "tiles and outputs resident in HBM",
-            "slices_per_gpu_per_step": n_sl, "patches_per_step_per_gpu": B, "coords_per_patch": 576,
+            "slices_per_gpu_per_step": n_sl, "patches_per_step_per_gpu": B, "patches_evaluated_per_step_per_gpu": evaluated,
+            "coords_per_patch": 576,
             "dim_hidden": H, "num_layers": L, "latent_dim": Z, "residual": deep, "activation": args.activation, "precision": args.precision, "streams": args.streams,
             "pipeline": args.pipeline, "brain_mask": bool(args.brain_mask),
             "parallelism": f"patch-shard x{world}",
