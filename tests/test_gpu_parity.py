@@ -574,3 +574,39 @@ def test_tiling_kernels_ragged_sizes_vs_oracle():
     for bad in ((8, 40), (17, 17)):
         with pytest.raises((ValueError, RuntimeError)):
             m.reconstruct(np.ones(bad, np.float32))
+
+
+def test_two_handles_from_two_threads():
+    """thread-compatible, re-entrant across handles.  Two models with different weights (and
+    different trunks: f16x3 work-queue kernel / fp32 kernel) are driven concurrently from two host threads
+    (ctypes drops the GIL inside the library); every result equals the model's own single-threaded output."""
+    import threading
+
+    models, tiles, refs = [], [], []
+    for seed, prec in ((7, "f16x3"), (8, "fp32")):
+        sd = syn.make_state_dict(seed=seed, trained_like=True)
+        m = make_model(sd, precision=prec)
+        t = np.random.default_rng(seed).random((300 + seed, 32, 32), dtype=np.float32)
+        models.append(m)
+        tiles.append(t)
+        refs.append(m(t))
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(15):
+                out = models[i](tiles[i])
+                if not np.array_equal(out, refs[i]):
+                    errors.append((i, float(np.abs(out - refs[i]).max())))
+                img = models[i].reconstruct(syn.make_slice(i, brain_mask=True))
+                if img.shape != (320, 320) or not np.isfinite(img).all():
+                    errors.append((i, "reconstruct"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors[:5]
