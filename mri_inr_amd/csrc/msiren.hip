@@ -555,8 +555,11 @@ int queue_for_launch(msiren_ctx* h, int64_t npasses, int** counter, unsigned* ba
     if (!c.queue.p) {
         int rc = ensure(h, c.queue, 256);
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync(c.queue.p, 0, 256, c.s));
-        c.queue_base = 0;
+        // test knob: start the never-reset counter just below 2^32 (or 2^31) to exercise its wrap-around
+        unsigned start = 0;
+        if (const char* e = std::getenv("MSIREN_QUEUE_START")) start = (unsigned)std::strtoul(e, nullptr, 0);
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c.queue.p, (int)start, 64, c.s));
+        c.queue_base = start;
     }
     *counter = (int*)c.queue.p;
     *base = c.queue_base;

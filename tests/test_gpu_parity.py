@@ -610,3 +610,34 @@ def test_two_handles_from_two_threads():
     for th in threads:
         th.join(timeout=300)
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize("start", ["0xFFFFF800", "0x7FFFF800"])
+def test_pass_counter_wraps_safely(start):
+    """The persistent trunks' pass counter is never reset (the host tells each launch the value it will find), so
+    after ~2^32 passes (minutes of continuous use) it wraps.  Started just below 2^32 / 2^31 (test knob
+    MSIREN_QUEUE_START, read when a handle's queue is created) the next launches cross the boundary: results must
+    not change, and nothing may hang."""
+    import subprocess
+    import sys
+    import textwrap
+
+    script = textwrap.dedent("""
+        import numpy as np
+        from mri_inr_amd import ModulatedSiren, synthetic as syn
+        from oracle import siren_oracle as orc
+        sd = syn.make_state_dict(seed=7, trained_like=True)
+        m = ModulatedSiren(2, 256, 1, 5, 256, 1.0, 30.0, True, 0.1, True, "custom", None, 32, 16, 24, "cuda", "sine")
+        m.load_state_dict(sd); m.to("cuda")
+        tiles = np.random.default_rng(2).random((400, 32, 32), dtype=np.float32)
+        ref = orc.modulated_siren_forward(sd, tiles[:32], num_layers=5, dtype=np.float64)
+        first = m(tiles)                       # 2 x 900 passes per call: the counter wraps within two calls
+        assert np.abs(first[:32] - ref).max() / np.abs(ref).max() < 1e-4
+        for _ in range(6):
+            assert np.array_equal(m(tiles), first)
+        print("WRAP OK")
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MSIREN_QUEUE_START=start)
+    r = subprocess.run([sys.executable, "-c", script], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "WRAP OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
