@@ -36,8 +36,8 @@ F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (no sparsity)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--slices", type=int, default=1, help="320x320 slices per GPU per step")
     ap.add_argument("--activation", default="sine", choices=["sine", "morlet"])
     ap.add_argument("--model", default="baseline", choices=["baseline", "deep_residual"],
