@@ -252,7 +252,8 @@ def test_f16x3_trunk_vs_reference_fixtures(act):
         check(out.reshape(out.shape[0], -1), g[name])
 
 
-@pytest.mark.parametrize("L,S,B", [(5, 24, 400), (5, 24, 7), (2, 24, 5), (3, 10, 9), (4, 24, 1030), (6, 8, 33)])
+@pytest.mark.parametrize("L,S,B", [(5, 24, 400), (5, 24, 7), (2, 24, 5), (3, 10, 9), (4, 24, 1030), (6, 8, 33), (8, 24, 50),
+                                   (11, 24, 20)])
 def test_f16x3_trunk_vs_oracle_shapes(L, S, B):
     sd = syn.make_state_dict(seed=4, num_layers=L, siren_patch_size=S, with_encoder=False)
     sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
