@@ -22,16 +22,16 @@ for _ in range(3):
     _lib.check(m._lib.msiren_f16x3_timeline(m._h, d_m.ptr, B, d_o.ptr, st.ctypes.data))
 t = st.astype(np.int64)
 valid = t[:, :, 6] != 0
-names = ["loads+layer0", "hidden1", "hidden2", "hidden3", "hidden4", "final+store"]
-d = np.diff(t[:, :, :7], axis=2)
+# stamps: 0 pass start, 1 layer 0 done, 2 hidden layers done, 6 pass end (s_memtime), 7 pass end (s_memrealtime),
+#         8..39 end of each of the 32 hidden-layer tiles
 print("passes recorded:", int(valid.sum()), "per WG:", np.bincount(valid.sum(1)))
-for i, n in enumerate(names):
-    x = d[:, :, i][valid]
+for n, a, b in (("loads+layer0", 0, 1), ("hidden layers", 1, 2), ("final+store", 2, 6)):
+    x = (t[:, :, b] - t[:, :, a])[valid]
     print(f"  {n:14s} median {int(np.median(x)):7d}  p10 {int(np.percentile(x,10)):7d}  p90 {int(np.percentile(x,90)):7d} cycles")
 tiles = np.diff(t[:, :, 8:40], axis=2)
-print("  per-tile cycles (median over WGs/passes), 32 tiles = 4 layers x 8:")
+print("  per-tile cycles (median over WGs/passes), tiles 1..31 of 4 layers x 8 (stamping itself costs ~20 %):")
 med = np.median(tiles[valid], axis=0).astype(int)
-print("   ", list(med))
+print("   ", [int(v) for v in med])
 tot = (t[:, :, 6] - t[:, :, 0])[valid]
 print("  pass total     median", int(np.median(tot)), " (ideal MFMA: 49152)")
 # clock: pass-end realtime differences between consecutive passes of the same WG
