@@ -1,0 +1,78 @@
+"""The C ABI consumed from plain C (examples/c_consumer.c, gcc -std=c99): no Python, no torch in the process.
+
+CPU: it compiles against include/msiren.h, links libmsiren.so and -- with no device -- fails loudly at
+msiren_create.  GPU: it loads a state_dict, evaluates msiren_forward_mods and must reproduce the reference's
+own output (tests/golden/trunk_sine.npz) within the 1e-4 gate.
+"""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, nerr
+from mri_inr_amd import _lib, synthetic as syn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path):
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not installed")
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    exe = str(tmp_path / "c_consumer")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    cmd = [gcc, "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "c_consumer.c"), "-L", libdir, "-lmsiren", f"-Wl,-rpath,{libdir}", "-lm", "-o", exe]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return exe
+
+
+def _write_inputs(tmp_path, sd, mods):
+    w = tmp_path / "weights.bin"
+    with open(w, "wb") as f:
+        for k, v in sd.items():
+            if k.startswith(("encoder", "modulator")):
+                continue  # the trunk entry point needs net.* and grid only
+            a = np.ascontiguousarray(v, dtype=np.float32).reshape(-1)
+            name = k.encode()
+            f.write(struct.pack("<i", len(name)) + name + struct.pack("<q", a.size) + a.tobytes())
+    m = tmp_path / "mods.bin"
+    with open(m, "wb") as f:
+        f.write(struct.pack("<iii", *mods.shape) + np.ascontiguousarray(mods, dtype=np.float32).tobytes())
+    return str(w), str(m), str(tmp_path / "out.bin")
+
+
+def test_c_consumer_builds_and_fails_loudly_without_a_device(tmp_path):
+    import torch
+
+    exe = _build(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test")
+    sd = syn.make_state_dict(seed=7)
+    w, m, o = _write_inputs(tmp_path, sd, syn.make_mods(1, 5, 2, 256))
+    res = subprocess.run([exe, w, m, o], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 2 and "msiren_create" in res.stderr, (res.returncode, res.stderr)
+    assert not os.path.exists(o)
+
+
+@pytest.mark.gpu
+def test_c_consumer_reproduces_the_reference_fixture(tmp_path):
+    exe = _build(tmp_path)
+    g = load_golden("trunk_sine.npz")  # outputs of the reference itself (oracle/gen_fixtures.py)
+    sd = syn.make_state_dict(seed=7)
+    mods = syn.make_mods(32, 5, 64, 256)
+    ref = g["uniform_B64"]
+    w, m, o = _write_inputs(tmp_path, sd, mods)
+    res = subprocess.run([exe, w, m, o], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    with open(o, "rb") as f:
+        B, P = struct.unpack("<ii", f.read(8))
+        out = np.frombuffer(f.read(), dtype=np.float32).reshape(B, P)
+    assert (B, P) == (mods.shape[1], 576)
+    assert nerr(out, ref) < 1e-4
