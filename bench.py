@@ -249,19 +249,22 @@ def main():
     if args.precision == "f16x3":
         # 3 fp16 MFMAs per algorithmic multiply-add: the bound for ALGORITHMIC FLOPs is the dense fp16
         # MFMA peak / 3.  The fp32-MFMA peak the north star names is reported next to it.
-        dtype, peak = "f16x3 (split-fp16 MFMA, fp32 accumulate; fp32-equivalent accuracy)", F16_MFMA_PEAK_TFLOPS / 3.0
+        dtype, peak = "f16x3", F16_MFMA_PEAK_TFLOPS / 3.0
+        dtype_note = "split-fp16: hi/lo fp16 operands, three fp16 MFMAs per product, fp32 accumulate; fp32-equivalent accuracy (1e-4 gate)"
         kernel = "siren_trunk_f16x3_kernel<%d,4>" % (1 if args.activation == "morlet" else 0)
     elif args.precision in ("bf16", "f16"):
-        dtype, peak = f"{args.precision} operands, fp32 accumulate", F16_MFMA_PEAK_TFLOPS
+        dtype, peak = args.precision, F16_MFMA_PEAK_TFLOPS
+        dtype_note = f"{args.precision} MFMA operands, fp32 accumulate"
         kernel = "siren_trunk_x1_kernel<%d,%d,%d,3>" % (args.precision == "bf16", args.activation == "morlet", deep)
     else:
         dtype, peak = "f32", FP32_MFMA_PEAK_TFLOPS
+        dtype_note = "fp32 MFMA (exact fp32 products and accumulation)"
         kernel = "siren_trunk_f32_kernel<%d,%d,%d,0>" % (H, args.activation == "morlet", deep)
     result = {
         "metric": "Mpixels/sec reconstructed (320x320 slice, hidden=256, 5 layers)",
         "value": value, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": dtype, "dtype_note": dtype_note, "data": "synthetic",
         "config": {
             "workload": f"BASELINE configs[{4 if deep else 1}]{' (deep residual 10x512, own semantics)' if deep else ''}: {n_sl} x 320x320 slice per GPU per step -> {B} tiles 32x32 -> "
                         f"ModulatedSiren.forward (encoder+modulator+fused trunk, {args.activation}) -> {B}x24x24; "
