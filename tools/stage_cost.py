@@ -29,10 +29,10 @@ d_out = [m.device_array((B, 24, 24)) for _ in range(2)]
 # latents and mods of these tiles, produced by the library itself
 _lib.check(lib.msiren_forward_tiles_dev(h, d_tiles.ptr, B, d_out[0].ptr))
 m.sync()
-z = np.asarray(m.forward_latent(np.zeros((1, 256), np.float32)))  # warm path
-from oracle import siren_oracle as orc  # checker-side helper only: inputs for the partial entry points
-zz = orc.encoder_forward(sd, tiles, dtype=np.float32).astype(np.float32)
-mods = np.stack(orc.modulator_forward(sd, zz, num_layers=5, dtype=np.float32)).astype(np.float32)
+# inputs of the partial entry points: timing only, so seeded synthetic latents / modulations (same shapes and
+# ranges as the model's own) -- the oracle is not imported outside tests/ and bench.py
+zz = (np.random.default_rng(1).standard_normal((B, 256)) * 0.3).astype(np.float32)
+mods = syn.make_mods(5, 5, B, 256)
 d_z.copy_from(zz)
 d_mods.copy_from(mods)
 
