@@ -73,3 +73,12 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "from oracle" not in src and "import oracle" not in src, f
+    # ... nor the evaluation driver, the diagnostic tools or the examples (bench.py uses it as checker / CPU baseline
+    # only, __graft_entry__.smoke() as checker)
+    repo = os.path.dirname(root)
+    extra = [os.path.join(repo, "test_mod_siren.py")]
+    for sub in ("tools", "examples"):
+        extra += [os.path.join(repo, sub, f) for f in os.listdir(os.path.join(repo, sub)) if f.endswith((".py", ".c", ".hip"))]
+    for path in extra:
+        src = open(path).read()
+        assert "from oracle" not in src and "import oracle" not in src, path
