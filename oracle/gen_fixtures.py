@@ -135,6 +135,27 @@ def _run_net_layers(model, mods):
     return hid, out
 
 
+GEOMETRIES = ((8, 16), (16, 32), (32, 32), (16, 20))
+
+
+def write_tiling_geometries(rt, torch):
+    """(4c) tiling / weighted fold for other (inner_patch_size, siren_patch_size) pairs of the YAML surface
+    (outer stays 32), on a 96x80 slice: patch geometry, per-patch means and the folded image."""
+    from mri_inr_amd import synthetic as syn
+
+    store = {}
+    img = syn.make_slice(2, 96, 80, brain_mask=True)
+    for inner, S in GEOMETRIES:
+        patches, info = rt.image_to_patches(torch.from_numpy(img)[None], 32, inner)
+        rec = np.random.default_rng(6).random((patches.shape[0], S, S), dtype=np.float32)
+        out = rt.patches_to_image_weighted_average(torch.from_numpy(rec), info, S, inner, torch.device("cpu")).numpy()
+        store[f"info_{inner}_{S}"] = np.array(info[0])
+        store[f"patch_means_{inner}_{S}"] = patches.numpy().reshape(patches.shape[0], -1).mean(1, dtype=np.float64)
+        store[f"wfold_{inner}_{S}"] = np.squeeze(out)
+    np.savez_compressed(os.path.join(GOLD, "tiling_geometries.npz"), **store)
+    return sorted(store)
+
+
 def main():
     import torch
 
@@ -221,6 +242,8 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "tiling.npz"), **store)
     manifest["cases"]["tiling"] = sorted(store)
 
+    manifest["cases"]["tiling_geometries"] = write_tiling_geometries(rt, torch)
+
     # ---- (4b) whole-slice reconstruction as metrics_error drives it (error.py:231-249) --------
     sdg = syn.make_state_dict(seed=7, trained_like=True)
     model = _build_reference_model(ModulatedSiren, FixedAutoencoder, sdg, H=H, L=L, Z=Z, S=S, activation="sine")
@@ -267,4 +290,15 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["geometries"]:  # add this one file without regenerating the others
+        sys.path.insert(0, REPO)
+        _rt = _import_reference()[2]
+        import torch
+        keys = write_tiling_geometries(_rt, torch)
+        mpath = os.path.join(GOLD, "MANIFEST.json")
+        man = json.load(open(mpath))
+        man["cases"]["tiling_geometries"] = keys
+        json.dump(man, open(mpath, "w"), indent=1, sort_keys=True)
+        print("wrote tiling_geometries.npz", keys)
+    else:
+        main()

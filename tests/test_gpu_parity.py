@@ -642,3 +642,33 @@ def test_pass_counter_wraps_safely(start):
     env = dict(os.environ, MSIREN_QUEUE_START=start)
     r = subprocess.run([sys.executable, "-c", script], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "WRAP OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("inner,S", [(8, 16), (16, 32), (32, 32), (16, 20)])
+def test_slice_pipeline_other_tiling_geometries(inner, S):
+    """The YAML surface lets inner_patch_size / siren_patch_size vary (outer stays 32: the custom encoder is
+    hard-wired to 32x32 tiles).  Tiling, black filter, forward and weighted fold against the oracle."""
+    sd = syn.make_state_dict(seed=5, siren_patch_size=S, trained_like=True)
+    m = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=inner, siren_patch_size=S, device="cuda", activation="sine")
+    m.load_state_dict(sd)
+    m.to("cuda").eval()
+    img = syn.make_slice(2, 96, 80, brain_mask=True)
+    got = m.reconstruct(img)
+    ref = orc.reconstruct_slice(sd, img, num_layers=5, outer=32, inner=inner, siren_patch_size=S, dtype=np.float64)
+    assert got.shape == ref.shape
+    assert nerr(got, ref) < 1e-4, nerr(got, ref)
+    # the fold kernel alone against the REFERENCE's output for this geometry (tests/golden/tiling_geometries.npz)
+    import ctypes as C
+
+    from mri_inr_amd import _lib
+
+    g = load_golden("tiling_geometries.npz")
+    nv, nh = (int(v) for v in g[f"info_{inner}_{S}"])
+    rec = np.random.default_rng(6).random((nv * nh, S, S), dtype=np.float32)
+    d_r = m.device_array(rec.shape).copy_from(rec)
+    d_o = m.device_array((1, nv * inner, nh * inner))
+    _lib.check(m._lib.msiren_weighted_fold_dev(m._h, d_r.ptr, 1, nv, nh, d_o.ptr))
+    m.sync()
+    assert nerr(d_o.numpy()[0], g[f"wfold_{inner}_{S}"]) < 2e-6

@@ -144,3 +144,18 @@ def test_tiling_refuses_images_too_small_for_reflect_padding():
             orc.image_to_patches(np.ones(bad, np.float32), 32, 16)
     patches, info = orc.image_to_patches(np.ones((16, 25), np.float32), 32, 16)
     assert patches.shape == (2, 32, 32) and tuple(info) == (1, 2)
+
+
+def test_tiling_other_geometries_vs_reference():
+    """inner_patch_size / siren_patch_size other than 16 / 24 (outer 32): patch grid, patch contents (means) and
+    the weighted fold against outputs of the reference's tiling.py (tests/golden/tiling_geometries.npz)."""
+    g = load_golden("tiling_geometries.npz")
+    img = syn.make_slice(2, 96, 80, brain_mask=True)
+    for inner, S in ((8, 16), (16, 32), (32, 32), (16, 20)):
+        patches, info = orc.image_to_patches(img, 32, inner)
+        assert tuple(info) == tuple(g[f"info_{inner}_{S}"])
+        assert np.array_equal(patches.reshape(patches.shape[0], -1).mean(1, dtype=np.float64), g[f"patch_means_{inner}_{S}"])
+        rec = np.random.default_rng(6).random((patches.shape[0], S, S), dtype=np.float32)
+        out = orc.patches_to_image_weighted_average(rec, info, S, inner)
+        assert out.shape == g[f"wfold_{inner}_{S}"].shape
+        assert nerr(out, g[f"wfold_{inner}_{S}"]) < 1e-6
