@@ -92,7 +92,7 @@ def _import_reference():
 
 
 def _build_reference_model(ModulatedSiren, FixedAutoencoder, sd, *, H, L, Z, S, activation,
-                           w0=1.0, w0_initial=30.0):
+                           w0=1.0, w0_initial=30.0, use_bias=True):
     import torch
 
     with tempfile.TemporaryDirectory() as td:
@@ -100,7 +100,7 @@ def _build_reference_model(ModulatedSiren, FixedAutoencoder, sd, *, H, L, Z, S, 
         torch.save({"state_dict": FixedAutoencoder().state_dict()}, ckpt)
         model = ModulatedSiren(
             dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=w0,
-            w0_initial=w0_initial, use_bias=True, dropout=0.1, modulate=True,
+            w0_initial=w0_initial, use_bias=use_bias, dropout=0.1, modulate=True,
             encoder_type="custom", encoder_path=ckpt, outer_patch_size=32, inner_patch_size=16,
             siren_patch_size=S, device=torch.device("cpu"), activation=activation)
     tsd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
@@ -133,6 +133,36 @@ def _run_net_layers(model, mods):
             hid.append(x.numpy().copy())
         out = model.net.last_layer(x).squeeze(2).numpy()
     return hid, out
+
+
+VARIANTS = {  # name: model hyper-parameters off the YAML defaults
+    "w0": dict(H=256, L=5, Z=256, S=24, activation="sine", w0=2.0, w0_initial=15.0, use_bias=True),
+    "nobias": dict(H=256, L=5, Z=256, S=24, activation="sine", w0=1.0, w0_initial=30.0, use_bias=False),
+    "small": dict(H=128, L=3, Z=256, S=10, activation="sine", w0=1.0, w0_initial=30.0, use_bias=True),
+    "morlet_w0": dict(H=256, L=5, Z=256, S=24, activation="morlet", w0=1.5, w0_initial=20.0, use_bias=True),
+    "deep": dict(H=256, L=8, Z=256, S=24, activation="sine", w0=1.0, w0_initial=30.0, use_bias=True),
+}
+
+
+def write_model_variants(ModulatedSiren, FixedAutoencoder, torch):
+    """(2b) the reference on hyper-parameters other than the YAML defaults: non-unit frequencies, no biases, a
+    small and a deeper network, Morlet with non-unit frequencies -- trunk on seeded modulations and full forward
+    on seeded tiles (6 each)."""
+    from mri_inr_amd import synthetic as syn
+
+    store = {}
+    for i, (name, v) in enumerate(VARIANTS.items()):
+        sd = syn.make_state_dict(seed=21 + i, dim_hidden=v["H"], num_layers=v["L"], latent_dim=v["Z"],
+                                 siren_patch_size=v["S"], use_bias=v["use_bias"], trained_like=True)
+        model = _build_reference_model(ModulatedSiren, FixedAutoencoder, sd, **v)
+        mods = syn.make_mods(50 + i, v["L"], 6, v["H"])
+        store[f"{name}_trunk"] = _run_net(model, mods)
+        tiles = np.random.default_rng(60 + i).random((6, 32, 32), dtype=np.float32)
+        with torch.no_grad():
+            store[f"{name}_forward"] = model(torch.from_numpy(tiles)).numpy()
+    store["meta"] = np.array(json.dumps(VARIANTS))
+    np.savez_compressed(os.path.join(GOLD, "model_variants.npz"), **store)
+    return sorted(store)
 
 
 GEOMETRIES = ((8, 16), (16, 32), (32, 32), (16, 20))
@@ -243,6 +273,7 @@ def main():
     manifest["cases"]["tiling"] = sorted(store)
 
     manifest["cases"]["tiling_geometries"] = write_tiling_geometries(rt, torch)
+    manifest["cases"]["model_variants"] = write_model_variants(ModulatedSiren, FixedAutoencoder, torch)
 
     # ---- (4b) whole-slice reconstruction as metrics_error drives it (error.py:231-249) --------
     sdg = syn.make_state_dict(seed=7, trained_like=True)
@@ -290,15 +321,20 @@ def main():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["geometries"]:  # add this one file without regenerating the others
+    if sys.argv[1:] in (["geometries"], ["variants"]):  # add one file without regenerating the others
         sys.path.insert(0, REPO)
-        _rt = _import_reference()[2]
+        _ms, _ae, _rt = _import_reference()
         import torch
-        keys = write_tiling_geometries(_rt, torch)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        if sys.argv[1] == "geometries":
+            key, keys = "tiling_geometries", write_tiling_geometries(_rt, torch)
+        else:
+            key, keys = "model_variants", write_model_variants(_ms, _ae, torch)
         mpath = os.path.join(GOLD, "MANIFEST.json")
         man = json.load(open(mpath))
-        man["cases"]["tiling_geometries"] = keys
+        man["cases"][key] = keys
         json.dump(man, open(mpath, "w"), indent=1, sort_keys=True)
-        print("wrote tiling_geometries.npz", keys)
+        print("wrote", key, keys)
     else:
         main()

@@ -672,3 +672,32 @@ def test_slice_pipeline_other_tiling_geometries(inner, S):
     _lib.check(m._lib.msiren_weighted_fold_dev(m._h, d_r.ptr, 1, nv, nh, d_o.ptr))
     m.sync()
     assert nerr(d_o.numpy()[0], g[f"wfold_{inner}_{S}"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["w0", "nobias", "small", "morlet_w0", "deep"])
+def test_model_variants_vs_reference_fixtures(name):
+    """The HIP path on hyper-parameters off the YAML defaults, against outputs of the reference itself
+    (tests/golden/model_variants.npz): trunk on seeded modulations and full forward on seeded tiles."""
+    from test_oracle_golden import _variant
+
+    g = load_golden("model_variants.npz")
+    v, sd, mods, tiles = _variant(name, g)
+    m = ModulatedSiren(dim_in=2, dim_hidden=v["H"], dim_out=1, num_layers=v["L"], latent_dim=v["Z"], w0=v["w0"],
+                       w0_initial=v["w0_initial"], use_bias=v["use_bias"], dropout=0.1, modulate=True,
+                       encoder_type="custom", encoder_path=None, outer_patch_size=32, inner_patch_size=16,
+                       siren_patch_size=v["S"], device="cuda", activation=v["activation"])
+    m.load_state_dict(sd)
+    m.to("cuda").eval()
+    kw = dict(num_layers=v["L"], w0=v["w0"], w0_initial=v["w0_initial"], activation=v["activation"],
+              siren_patch_size=v["S"], dtype=np.float64)
+    for got, ref, truth in ((m.forward_mods(mods).reshape(6, -1), g[f"{name}_trunk"], orc.siren_forward(sd, mods, **kw)),
+                            (m(tiles), g[f"{name}_forward"], orc.modulated_siren_forward(sd, tiles, **kw))):
+        assert got.shape == ref.shape and got.dtype == np.float32 and np.isfinite(got).all()
+        # The north star's tolerance against the reference's output -- unless the reference's own fp32 arithmetic is
+        # further than that from the fp64 result (w0 = 2 doubles every hidden sine argument: torch-fp32 is 7-8e-5
+        # away from fp64 there, 3e-6 on the other variants; two such results may differ by the sum) ...
+        floor = nerr(ref, truth)
+        assert nerr(got, ref) <= max(1e-4, 2.0 * floor), (nerr(got, ref), floor)
+        # ... and at least about as close to the fp64 result as the reference is
+        assert nerr(got, truth) <= max(2e-5, 1.5 * floor), (nerr(got, truth), floor)
+        assert rms(got, ref) <= max(1e-5, 2.0 * rms(ref, truth)), (rms(got, ref), rms(ref, truth))
