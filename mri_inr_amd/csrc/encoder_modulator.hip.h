@@ -109,10 +109,13 @@ __global__ __launch_bounds__(256, 5) void encoder_kernel(EncoderParams p, const 
 // conv1 + conv2 of the encoder only: one workgroup per tile, writes the flattened conv2 output
 // (c, y, x) -> feat[tile][2048]; conv3 and the Linear follow as batched MFMA GEMMs (linear_mfma_kernel).
 __global__ __launch_bounds__(256, 5) void encoder_conv_kernel(EncoderParams p, const float* __restrict__ tiles, float* __restrict__ feat) {
-    constexpr int RS = 20;  // conv1 rows padded from 17 to 20 floats: every row starts 16-byte aligned
-    __shared__ float t0[33 * 33];                                    // input with a zero row/column in front (padding = 1)
-    __shared__ __attribute__((aligned(16))) float a1[16 * 17 * RS];  // conv1 output, same front padding for conv2
-    typedef float f4 __attribute__((ext_vector_type(4)));
+    // conv1 output with conv2's front padding (17 x 17 per channel), columns de-interleaved into an even and an odd
+    // plane of row stride 12: the stride-2 convolution then reads unit-stride along x, and a wave's 64 output
+    // positions (8 x 8) fall on 32 different banks twice (bank = x - 8y mod 32) -- no conflict beyond the 2 passes a
+    // 64-lane ds_read_b32 takes anyway.
+    constexpr int RSP = 12, PLANE = 17 * RSP;
+    __shared__ float t0[33 * 33];            // input with a zero row/column in front (padding = 1)
+    __shared__ float a1[16 * 2 * PLANE];     // [channel][column parity][row][column >> 1]
     const int tid = threadIdx.x;
     if (p.plan && (int)blockIdx.x >= p.plan[0]) return;  // workgroup-uniform
     const float* tile = tiles + (size_t)(p.plan ? p.plan[2 + blockIdx.x] : (int)blockIdx.x) * 1024;
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256, 5) void encoder_conv_kernel(EncoderParams p, c
         const int y = i / 33, x = i - y * 33;
         t0[i] = (y == 0 || x == 0) ? 0.f : tile[(y - 1) * 32 + (x - 1)];
     }
-    for (int i = tid; i < 16 * 17 * RS / 4; i += 256) reinterpret_cast<f4*>(a1)[i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 16 * 2 * PLANE; i += 256) a1[i] = 0.f;
     __syncthreads();
     for (int i = tid; i < 16 * 256; i += 256) {
         const int c = i >> 8, y = (i >> 4) & 15, x = i & 15;
@@ -130,44 +133,33 @@ __global__ __launch_bounds__(256, 5) void encoder_conv_kernel(EncoderParams p, c
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) s = __builtin_fmaf(t0[(2 * y + ky) * 33 + 2 * x + kx], p.c1w[c * 9 + ky * 3 + kx], s);
-        a1[(c * 17 + y + 1) * RS + (x + 1)] = leaky02(s);
+        const int col = x + 1;  // padded column
+        a1[(c * 2 + (col & 1)) * PLANE + (y + 1) * RSP + (col >> 1)] = leaky02(s);
     }
     __syncthreads();
-    // conv2: thread = (output channel, output row), 8 outputs along x in registers.  Per (input channel, ky)
-    // the 17 inputs of the row are read once (5 broadcast ds_read_b128: the address depends on the output row
-    // only) and feed 3 kx x 8 outputs; accumulation order (c, ky, kx) as in the fused kernel: same bits.
-    const int o = tid & 31, y = tid >> 5;
+    // conv2: lane = output position (8 x 8), wave = 8 of the 32 output channels.  The weights of a tap are the same
+    // for the whole wave: 8 consecutive floats at a wave-uniform address (scalar loads), one LDS read of the lane's
+    // input feeds 8 FMAs.  Accumulation order (c, ky, kx) as in the fused kernel: same bits.
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, y = lane >> 3, x = lane & 7;
     float s[8];
 #pragma unroll
-    for (int x = 0; x < 8; ++x) s[x] = p.c2b[o];
+    for (int j = 0; j < 8; ++j) s[j] = p.c2b[8 * wv + j];
     for (int c = 0; c < 16; ++c)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const f4* row = reinterpret_cast<const f4*>(&a1[(c * 17 + 2 * y + ky) * RS]);
-            float r[RS];
+            const float* even = &a1[(c * 2 + 0) * PLANE + (2 * y + ky) * RSP + x];  // padded columns 2x, 2x+2
+            const float* odd = &a1[(c * 2 + 1) * PLANE + (2 * y + ky) * RSP + x];   // padded column 2x+1
+            const float in[3] = {even[0], odd[0], even[1]};
 #pragma unroll
-            for (int q = 0; q < RS / 4; ++q) {
-                const f4 v = row[q];
-                r[4 * q] = v[0];
-                r[4 * q + 1] = v[1];
-                r[4 * q + 2] = v[2];
-                r[4 * q + 3] = v[3];
-            }
-            const float w0 = p.c2w[(c * 9 + ky * 3 + 0) * 32 + o];
-            const float w1 = p.c2w[(c * 9 + ky * 3 + 1) * 32 + o];
-            const float w2 = p.c2w[(c * 9 + ky * 3 + 2) * 32 + o];
+            for (int kx = 0; kx < 3; ++kx) {
+                const float* w = p.c2w + (c * 9 + ky * 3 + kx) * 32 + 8 * wv;
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                s[x] = __builtin_fmaf(r[2 * x], w0, s[x]);
-                s[x] = __builtin_fmaf(r[2 * x + 1], w1, s[x]);
-                s[x] = __builtin_fmaf(r[2 * x + 2], w2, s[x]);
+                for (int j = 0; j < 8; ++j) s[j] = __builtin_fmaf(in[kx], w[j], s[j]);
             }
         }
-    float* dst = feat + (size_t)blockIdx.x * 2048 + o * 64 + y * 8;
-    f4 lo = {leaky02(s[0]), leaky02(s[1]), leaky02(s[2]), leaky02(s[3])};
-    f4 hi = {leaky02(s[4]), leaky02(s[5]), leaky02(s[6]), leaky02(s[7])};
-    *reinterpret_cast<f4*>(dst) = lo;
-    *reinterpret_cast<f4*>(dst + 4) = hi;
+    float* dst = feat + (size_t)blockIdx.x * 2048 + (8 * wv) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j * 64] = leaky02(s[j]);
 }
 
 // ---- modulator ----------------------------------------------------------------------------------
