@@ -701,3 +701,32 @@ def test_model_variants_vs_reference_fixtures(name):
         # ... and at least about as close to the fp64 result as the reference is
         assert nerr(got, truth) <= max(2e-5, 1.5 * floor), (nerr(got, truth), floor)
         assert rms(got, ref) <= max(1e-5, 2.0 * rms(ref, truth)), (rms(got, ref), rms(ref, truth))
+
+
+def test_tiling_roundtrip_property_on_device():
+    """Size-independent property through the device kernels: tiles cut from one image by image_to_patches_dev are
+    mutually consistent, so the weighted fold of their 24x24 centres returns the image on [0, H) x [0, W) -- at the
+    BASELINE slice size, several slices per call, and ragged sizes."""
+    import ctypes as C
+
+    from mri_inr_amd import _lib
+
+    sd = syn.make_state_dict(seed=7)
+    m = make_model(sd)
+    rng = np.random.default_rng(3)
+    for n, hh, ww in ((1, 320, 320), (5, 320, 320), (2, 200, 136), (3, 37, 81)):
+        imgs = rng.random((n, hh, ww), dtype=np.float32)
+        nv, nh = C.c_int32(), C.c_int32()
+        _lib.check(m._lib.msiren_recon_shape(m._h, hh, ww, C.byref(nv), C.byref(nh)))
+        per = nv.value * nh.value
+        d_img = m.device_array(imgs.shape).copy_from(imgs)
+        d_p = m.device_array((n * per, 32, 32))
+        _lib.check(m._lib.msiren_image_to_patches_dev(m._h, d_img.ptr, n, hh, ww, d_p.ptr))
+        m.sync()
+        centres = np.ascontiguousarray(d_p.numpy()[:, 4:28, 4:28])
+        d_c = m.device_array(centres.shape).copy_from(centres)
+        d_o = m.device_array((n, nv.value * 16, nh.value * 16))
+        _lib.check(m._lib.msiren_weighted_fold_dev(m._h, d_c.ptr, n, nv.value, nh.value, d_o.ptr))
+        m.sync()
+        out = d_o.numpy()
+        assert np.abs(out[:, :hh, :ww] - imgs).max() < 1e-6, (n, hh, ww)

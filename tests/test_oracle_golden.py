@@ -189,3 +189,28 @@ def test_model_variants_vs_reference(name):
         floor = nerr(ref, truth)
         assert nerr(got, ref) <= max(2e-5, 1.5 * floor), (nerr(got, ref), floor)
         assert nerr(got, truth) <= max(2e-5, 2.0 * floor), (nerr(got, truth), floor)
+
+
+def _valid_size(n, inner=16, pad=8):
+    return pad + (inner - n % inner) % inner < n
+
+
+def test_tiling_roundtrip_property():
+    """Size-independent property of the tiling maths (any valid image size): tiles cut from one image are mutually
+    consistent, so both folds -- plain overlap average of the 32x32 tiles and the weighted fold of their 24x24
+    centres -- return that image on [0, H) x [0, W) (reflect padding beyond it)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=25, deadline=None)
+    @given(st.integers(16, 90).filter(_valid_size), st.integers(16, 90).filter(_valid_size), st.integers(0, 2**31 - 1))
+    def prop(hh, ww, seed):
+        img = np.random.default_rng(seed).random((hh, ww), dtype=np.float32)
+        patches, info = orc.image_to_patches(img, 32, 16)
+        plain = orc.patches_to_image(patches, info, 32, 16)
+        assert plain.shape == (info[0] * 16, info[1] * 16)
+        assert np.abs(plain[:hh, :ww] - img).max() < 1e-6
+        centres = orc.extract_center_batch(patches, 32, 24)
+        weighted = orc.patches_to_image_weighted_average(centres, info, 24, 16)
+        assert np.abs(weighted[:hh, :ww] - img).max() < 1e-6
+
+    prop()
