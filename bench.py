@@ -1,23 +1,38 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X modulated-SIREN path: Mpixels/s reconstructed (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # N > 1: starts its N ranks itself
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic input per GPU:
 ``ModulatedSiren.forward`` (encoder -> modulator -> fused SIREN trunk) on the 400 tiles
-(32x32 in, 24x24 out) of ``--slices`` 320x320 slice(s) (default 1 = BASELINE.json configs[1]),
-tiles already resident in HBM, outputs left in HBM.  Patches are independent, so with N GPUs
-every rank processes its own slices (weak scaling); the only collective on the path is the RCCL
-broadcast of the weight blob from rank 0 at load time, outside the timed region.
+(32x32 in, 24x24 out) of each 320x320 slice of the batch, tiles already resident in HBM, outputs left
+in HBM.  Two ways of sizing the batch:
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement for the fields).
-torch is used for process-group plumbing (RCCL/gloo) and device synchronisation only.
+  --slices S         S slices per GPU per step (default 1 = BASELINE.json configs[1]); per-GPU work is
+                     fixed as N grows                                          -> "scaling": "weak"
+  --total-slices T   a fixed batch of T slices per step (64 = BASELINE.json configs[2]), contiguous
+                     slice blocks sharded over the ranks (dist.shard_range)    -> "scaling": "strong"
+
+Patches are independent given the weights, so the path has no data-path collective: every rank
+evaluates its own slices; the only collective is the broadcast of the weights from rank 0 at load
+time (RCCL over xGMI), outside the timed region.  Started without a launcher and with --gpus N > 1
+the script launches its own N ranks (mri_inr_amd/launch.py: one child process per GPU, torchrun's
+environment contract); under torchrun it uses the environment it finds.  WORLD_SIZE != --gpus is
+an error in every case.
+
+Backends (MSIREN_BENCH_BACKEND): "rccl" (default) -- communicator, broadcast, barrier and MAX-reduce
+through libmsiren's C ABI (include/msiren.h, "multi-GPU"): no torch.distributed, one HIP runtime in
+the process; "nccl" -- the same over torch.distributed (RCCL); "gloo" -- torch.distributed on the CPU,
+which lets several ranks share one card to rehearse the N > 1 path on a 1-GPU box.
+
+Prints ONE JSON line on rank 0 (README / DESIGN.md §5 describe the fields).
 """
 
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -31,14 +46,18 @@ sys.path.insert(0, REPO)
 SUSTAINED_F16_MFMA_TFLOPS = 1476.0
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (= vector peak)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (no sparsity)
+MIN_WARMUP_S = 0.4             # untimed: the card needs a few hundred ms under load before its clock settles
+MIN_ROOFLINE_LAUNCHES = 200
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--slices", type=int, default=1, help="320x320 slices per GPU per step")
+    ap.add_argument("--slices", type=int, default=1, help="320x320 slices per GPU per step (weak scaling)")
+    ap.add_argument("--total-slices", type=int, default=0,
+                    help="fixed batch of this many slices per step, sharded over the ranks (strong scaling; 64 = BASELINE configs[2])")
     ap.add_argument("--activation", default="sine", choices=["sine", "morlet"])
     ap.add_argument("--model", default="baseline", choices=["baseline", "deep_residual"],
                     help="baseline = 5 x 256 (BASELINE configs 1-4); deep_residual = 10 x 512, latent 128, residual "
@@ -55,9 +74,11 @@ def parse():
                     help="elliptical brain-like mask on the synthetic slices (43 %% of the tiles become black; only "
                          "--pipeline reconstruct skips them, as the reference's black-patch filter does)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host->host and slice->slice rates after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--check", action="store_true", help="also verify one batch against the oracle")
-    return ap.parse_args()
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="self-launched ranks: wall limit of the whole job")
+    return ap.parse_args(argv)
 
 
 def effective_cores() -> int:
@@ -85,11 +106,14 @@ def traffic_bytes(kernel):
     """HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes (collected with
     tools/profile.sh: separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction); None if the
     profile on record is for another kernel."""
-    try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r1", "traffic.json")))
-        return d["bytes_per_launch"] if d.get("kernel") == kernel else None
-    except Exception:
-        return None
+    for rnd in ("r2", "r1"):
+        try:
+            d = json.load(open(os.path.join(REPO, "profiles", rnd, "traffic.json")))
+        except Exception:
+            continue
+        if d.get("kernel") == kernel:
+            return d["bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(sd, tiles, activation, budget_s):
@@ -118,133 +142,227 @@ def cpu_baseline(sd, tiles, activation, budget_s):
     }
 
 
+def workload_label(args, deep, n_total, world):
+    if deep:
+        cfg = "BASELINE configs[4] (deep residual 10x512, latent 128; own semantics, parity unpinned)"
+    elif args.activation == "morlet":
+        cfg = "BASELINE configs[3] (Morlet activation)"
+    elif args.total_slices:
+        cfg = f"BASELINE configs[2]: batch of {n_total} slices patch-sharded over {world} GPU(s)" if n_total == 64 else \
+              f"fixed batch of {n_total} slices sharded over {world} GPU(s) (BASELINE configs[2] shape)"
+    elif args.slices == 1:
+        cfg = "BASELINE configs[1]: one 320x320 slice"
+    else:
+        cfg = f"{args.slices} x BASELINE configs[1] (320x320 slices per GPU per step)"
+    return cfg
+
+
+class TorchGroup:
+    """torch.distributed plumbing (backends "nccl" = RCCL, "gloo"): same interface as dist.RcclGroup."""
+
+    def __init__(self, backend, rank, world, local_rank):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.backend, self.rank, self.world = torch, dist, backend, rank, world
+        self.device = torch.device("cuda", local_rank) if backend == "nccl" else None
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=self.device)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def broadcast_state_dict(self, sd):
+        from mri_inr_amd.dist import broadcast_state_dict
+
+        return broadcast_state_dict(sd, src=0, device=self.device) if self.world > 1 else sd
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, v):
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.device or "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def destroy(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    from mri_inr_amd import launch
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be positive")
+    if args.gpus > 1 and not launch.under_launcher():
+        # no launcher around us: become one.  Nothing in this process has touched HIP (or imported torch).
+        rc, _ = launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                   timeout=args.launch_timeout)
+        sys.exit(rc)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py without a launcher (it starts its "
+                         f"own ranks) or make the launcher's --nproc-per-node match")
+
     deep = args.model == "deep_residual"
     if args.precision is None:
         args.precision = "bf16" if deep else "f16x3"
     H, L, Z = (512, 10, 128) if deep else (256, 5, 256)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
-    import torch
-    import torch.distributed as dist
+    backend = os.environ.get("MSIREN_BENCH_BACKEND", "rccl")
+    if backend not in ("rccl", "nccl", "gloo"):
+        raise SystemExit(f"MSIREN_BENCH_BACKEND={backend}: expected rccl, nccl or gloo")
 
     from mri_inr_amd import ModulatedSiren, synthetic as syn
     from mri_inr_amd import _lib
-    from mri_inr_amd.dist import broadcast_state_dict
+    from mri_inr_amd.dist import RcclGroup, shard_range
 
-    if not torch.cuda.is_available():
+    tgroup = None
+    if backend != "rccl":
+        # torch's bundled HIP runtime has to come up before libmsiren's (mri_inr_amd/_lib.py)
+        import torch
+
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a gfx950 GPU (the HIP path has no CPU fallback)")
+        tgroup = TorchGroup(backend, rank, world, local_rank % torch.cuda.device_count())
+    ndev = _lib.device_count()
+    if ndev < 1:
         raise SystemExit("bench.py needs a gfx950 GPU (the HIP path has no CPU fallback)")
-    # one rank per GPU; MSIREN_BENCH_BACKEND=gloo lets several ranks share one card (rehearsal of the
-    # N > 1 code path on a 1-GPU box: RCCL refuses two ranks on the same device)
-    backend = os.environ.get("MSIREN_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    if backend != "gloo" and world > ndev:
+        raise SystemExit(f"{world} ranks but {ndev} GPU(s) visible: one rank per GPU (MSIREN_BENCH_BACKEND=gloo rehearses "
+                         f"several ranks on one card)")
+    dev = local_rank % ndev
 
     # ---- model: random-init weights of the named architecture; rank 0's copy is broadcast (RCCL) ----
     # deep residual model: modulations centred on 0.25 keep the 10-layer residual stream in the regime
     # where 16-bit operands are meaningful (with O(1) modulations it is chaotic: even fp32 is only 2e-4)
     kw = dict(modulator_bias_center=0.25, encoder_gain=10.0) if deep else dict(trained_like=True)
     sd = syn.make_state_dict(seed=7, dim_hidden=H, num_layers=L, latent_dim=Z, **kw) if rank == 0 else None
-    if world > 1:
-        sd = broadcast_state_dict(sd, src=0, device=torch.device("cuda", local_rank) if backend == "nccl" else None)
     model = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=1.0, w0_initial=30.0,
                            use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
                            outer_patch_size=32, inner_patch_size=16, siren_patch_size=24,
-                           device=f"cuda:{local_rank}", activation=args.activation, precision=args.precision, residual=deep)
-    model.load_state_dict(sd)
-    model.to(f"cuda:{local_rank}").eval()
+                           device=f"cuda:{dev}", activation=args.activation, precision=args.precision, residual=deep)
+    if tgroup is not None:
+        sd = tgroup.broadcast_state_dict(sd)
+        model.load_state_dict(sd)
+        model.to(f"cuda:{dev}").eval()
+        group = tgroup
+    else:
+        group = RcclGroup(model)          # communicator through the C ABI (no-op for one rank)
+        if rank == 0:
+            model._sd.update({k: np.ascontiguousarray(v, dtype=np.float32) for k, v in sd.items()})
+        group.broadcast_weights(0)        # load_state_dict on rank 0 only; one ncclBroadcast of the blob
+        model.eval()
     lib, h = model._lib, model._h
 
     # ---- synthetic input: slice k = default_rng(1000+k).random((320,320)), tiled 32/16 on the device ----
-    n_sl = args.slices
-    imgs = np.stack([syn.make_slice(rank * n_sl + k, brain_mask=args.brain_mask) for k in range(n_sl)])
+    if args.total_slices:
+        lo, hi = shard_range(args.total_slices, rank, world)
+        n_total, scaling = args.total_slices, "strong"
+    else:
+        lo, hi = rank * args.slices, (rank + 1) * args.slices
+        n_total, scaling = world * args.slices, "weak"
+    n_sl = hi - lo
     B = n_sl * 400
-    d_img = model.device_array(imgs.shape).copy_from(imgs)
-    d_tiles = model.device_array((B, 32, 32))
-    d_outs = [model.device_array((B, 24, 24)) for _ in range(2)]
-    d_out = d_outs[0]
-    d_recons = [model.device_array((n_sl, 320, 320)) for _ in range(2)] if args.pipeline == "reconstruct" else None
+    imgs = np.stack([syn.make_slice(k, brain_mask=args.brain_mask) for k in range(lo, hi)]) if n_sl else \
+        np.zeros((0, 320, 320), np.float32)
+    d_img = model.device_array((max(n_sl, 1), 320, 320))
+    d_tiles = model.device_array((max(B, 1), 32, 32))
+    d_outs = [model.device_array((max(B, 1), 24, 24)) for _ in range(2)]
+    d_recons = [model.device_array((max(n_sl, 1), 320, 320)) for _ in range(2)]
+    if n_sl:
+        _lib.check(lib.msiren_memcpy_h2d(h, d_img.ptr, imgs.ctypes.data, imgs.nbytes))
     _lib.check(lib.msiren_set_streams(h, args.streams))
     _lib.check(lib.msiren_image_to_patches_dev(h, d_img.ptr, n_sl, 320, 320, d_tiles.ptr))
     model.sync()
 
     nstep = [0]
 
-    def step():
-        # consecutive steps are independent slices: alternate the output buffer with the stream
-        if d_recons is not None:
-            _lib.check(lib.msiren_reconstruct_slices_dev(h, d_img.ptr, n_sl, 320, 320, d_recons[nstep[0] & 1].ptr))
-        else:
-            _lib.check(lib.msiren_forward_tiles_dev(h, d_tiles.ptr, B, d_outs[nstep[0] & 1].ptr))
+    def step_forward():
+        # consecutive steps are independent batches: alternate the output buffer with the stream
+        _lib.check(lib.msiren_forward_tiles_dev(h, d_tiles.ptr, B, d_outs[nstep[0] & 1].ptr))
         nstep[0] += 1
 
-    def fence():
-        model.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step_reconstruct():
+        _lib.check(lib.msiren_reconstruct_slices_dev(h, d_img.ptr, n_sl, 320, 320, d_recons[nstep[0] & 1].ptr))
+        nstep[0] += 1
 
+    step = step_reconstruct if args.pipeline == "reconstruct" else step_forward
+
+    def device_sync():
+        model.sync()  # hipStreamSynchronize on every stream the handle launches on
+        if tgroup is not None:
+            tgroup.torch.cuda.synchronize()
+
+    def fence():
+        device_sync()
+        group.barrier()
+        device_sync()
+
+    # ---- warm-up: W steps as asked, then (still untimed) until the card has been under load for MIN_WARMUP_S ----
+    t_w = time.perf_counter()
     for _ in range(args.warmup):
         step()
+    warm_steps = args.warmup
+    device_sync()
+    while time.perf_counter() - t_w < MIN_WARMUP_S:
+        for _ in range(16):
+            step()
+        warm_steps += 16
+        device_sync()
     fence()
-    import ctypes as C
 
     _lib.check(lib.msiren_profile_enable(h, 1))  # HIP events around every trunk launch, on its stream
     _lib.check(lib.msiren_timer_start(h))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    model.sync()
-    torch.cuda.synchronize()
+    device_sync()
     t1 = time.perf_counter()
     dev_ms = C.c_float()
     _lib.check(lib.msiren_timer_stop(h, C.byref(dev_ms)))
     launches, trunk_ms = C.c_int64(), C.c_double()
     _lib.check(lib.msiren_profile_read(h, C.byref(launches), C.byref(trunk_ms)))
     _lib.check(lib.msiren_profile_enable(h, 0))
-    elapsed = t1 - t0
+    elapsed_local = t1 - t0
+    group.barrier()
+    elapsed = group.max(elapsed_local)
     overlapped_trunk_ms = trunk_ms.value / max(launches.value, 1)
     n_over = int(launches.value)
-    if args.streams > 1:
+
+    if args.streams > 1 and B > 0:
         # With two streams the launches of consecutive steps overlap, so a launch's own duration says
-        # little about the kernel.  The roofline figure is therefore taken from a short single-stream
-        # phase of the same process (kernel alone on the device), after the timed region.
+        # little about the kernel.  The roofline figure is therefore taken from a single-stream phase of
+        # the same process (kernel alone on the device), after the timed region.
         _lib.check(lib.msiren_set_streams(h, 1))
-        for _ in range(3):
+        for _ in range(8):
             step()
         model.sync()
         _lib.check(lib.msiren_profile_enable(h, 1))
-        for _ in range(max(10, args.steps // 4)):
+        for _ in range(max(MIN_ROOFLINE_LAUNCHES, args.steps // 4) if n_sl <= 8 else max(20, args.steps // 4)):
             step()
         _lib.check(lib.msiren_profile_read(h, C.byref(launches), C.byref(trunk_ms)))
         _lib.check(lib.msiren_profile_enable(h, 0))
-    if world > 1:
-        dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        _lib.check(lib.msiren_set_streams(h, args.streams))
 
-    px_per_step = world * n_sl * 320 * 320
+    px_per_step = n_total * 320 * 320
     value = px_per_step * args.steps / elapsed / 1e6
     # the slice pipeline skips black tiles (mean < 1e-10, tiling.py:184-198): only evaluated tiles count as work
     evaluated = B
-    if d_recons is not None:
-        evaluated = int((d_tiles.numpy().reshape(B, -1).mean(axis=1, dtype=np.float32) >= np.float32(1e-10)).sum())
+    if args.pipeline == "reconstruct" and B:
+        evaluated = int((d_tiles.numpy()[:B].reshape(B, -1).mean(axis=1, dtype=np.float32) >= np.float32(1e-10)).sum())
     flops_launch = model.flops_per_coord() * evaluated * 576
     trunk_avg_s = trunk_ms.value / max(launches.value, 1) / 1e3
-    achieved = flops_launch / trunk_avg_s / 1e12
+    achieved = flops_launch / trunk_avg_s / 1e12 if trunk_avg_s > 0 else 0.0
 
     if args.precision == "f16x3":
         # 3 fp16 MFMAs per algorithmic multiply-add: the bound for ALGORITHMIC FLOPs is the dense fp16
@@ -260,20 +378,25 @@ def main():
         dtype, peak = "f32", FP32_MFMA_PEAK_TFLOPS
         dtype_note = "fp32 MFMA (exact fp32 products and accumulation)"
         kernel = "siren_trunk_f32_kernel<%d,%d,%d,0>" % (H, args.activation == "morlet", deep)
+    stage = ("slice -> tiles -> black filter -> encoder+modulator+fused trunk -> weighted fold -> slice, device-resident"
+             if args.pipeline == "reconstruct" else
+             f"ModulatedSiren.forward (encoder+modulator+fused trunk, {args.activation}) on resident tiles -> (B,24,24) in HBM")
     result = {
-        "metric": "Mpixels/sec reconstructed (320x320 slice, hidden=256, 5 layers)",
+        "metric": f"Mpixels/sec reconstructed (320x320 slice, hidden={H}, {L} layers)",
         "value": value, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": dtype, "dtype_note": dtype_note, "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[{4 if deep else 1}]{' (deep residual 10x512, own semantics)' if deep else ''}: {n_sl} x 320x320 slice per GPU per step -> {B} tiles 32x32 -> "
-                        f"ModulatedSiren.forward (encoder+modulator+fused trunk, {args.activation}) -> {B}x24x24; "
-                        "tiles and outputs resident in HBM",
-            "slices_per_gpu_per_step": n_sl, "patches_per_step_per_gpu": B, "patches_evaluated_per_step_per_gpu": evaluated,
-            "coords_per_patch": 576,
-            "dim_hidden": H, "num_layers": L, "latent_dim": Z, "residual": deep, "activation": args.activation, "precision": args.precision, "streams": args.streams,
-            "pipeline": args.pipeline, "brain_mask": bool(args.brain_mask),
-            "parallelism": f"patch-shard x{world}",
+            "workload": f"{workload_label(args, deep, n_total, world)}; per step {n_total} slice(s) = {n_total * 400} tiles 32x32 "
+                        f"over {world} GPU(s); {stage}",
+            "slices_per_step_total": n_total, "slices_per_step_rank0": n_sl, "patches_per_step_rank0": B,
+            "patches_evaluated_per_step_rank0": evaluated, "coords_per_patch": 576,
+            "dim_hidden": H, "num_layers": L, "latent_dim": Z, "residual": deep, "activation": args.activation,
+            "precision": args.precision, "streams": args.streams, "pipeline": args.pipeline, "brain_mask": bool(args.brain_mask),
+            "parallelism": f"slice-shard x{world} ({scaling}; no data-path collective, one weight broadcast at load)",
+            "backend": {"rccl": "RCCL through libmsiren's C ABI (torch-free)", "nccl": "torch.distributed nccl (RCCL)",
+                        "gloo": "torch.distributed gloo (rehearsal: ranks may share a card)"}[backend] if world > 1 else "single process",
+            "warmup_steps_run": warm_steps,
         },
         "roofline": {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -283,18 +406,18 @@ def main():
             # tools/mfma_peak_probe.hip: all 256 CUs issuing only fp16 MFMAs sustain 1476 TFLOP/s under the
             # board power limit (profiles/r1/10_*); context for `frac`, which is against the nominal peak
             "sustained_fp16_mfma_tflops_measured": SUSTAINED_F16_MFMA_TFLOPS,
-            "measured": "HIP event pairs on the kernel's stream; single-stream phase of this run (kernel alone)"
-                        if args.streams > 1 else "HIP event pairs on the kernel's stream inside the timed region",
+            "measured": "HIP event pairs on the kernel's stream; single-stream phase of this run (kernel alone), rank 0"
+                        if args.streams > 1 else "HIP event pairs on the kernel's stream inside the timed region, rank 0",
             "timed_region_avg_launch_ms": overlapped_trunk_ms, "timed_region_launches": n_over,
-            "pipelined_tflops": flops_launch * world * args.steps / elapsed / 1e12 / world,
-            "note": "achieved = algorithmic FLOPs (525824 per coordinate) / mean kernel time; for f16x3 the "
+            "pipelined_tflops_per_gpu": model.flops_per_coord() * 576 * 400 * n_total * args.steps / elapsed / 1e12 / world,
+            "note": "achieved = algorithmic FLOPs (525824 per coordinate at 256x5) / mean kernel time; for f16x3 the "
                     "kernel issues 3x that many fp16 MFMA FLOPs, hence peak = 2500/3",
         },
         "device_ms_per_step": dev_ms.value / args.steps,
     }
 
     if rank == 0:
-        if args.check and d_recons is not None:
+        if args.check and args.pipeline == "reconstruct":
             from oracle import siren_oracle as orc
 
             ref = orc.reconstruct_slice(sd, imgs[0], num_layers=L, activation=args.activation, dtype=np.float64)
@@ -303,13 +426,15 @@ def main():
         elif args.check:
             from oracle import siren_oracle as orc
 
-            got = d_out.numpy()[:64]
+            got = d_outs[(nstep[0] - 1) & 1].numpy()[:64]
             tiles_h = d_tiles.numpy()[:64]
             z = orc.encoder_forward(sd, tiles_h, dtype=np.float64)
             mods = orc.modulator_forward(sd, z, num_layers=L, dtype=np.float64)
             ref = orc.siren_forward(sd, mods, num_layers=L, activation=args.activation, residual=deep,
                                     dtype=np.float64).reshape(-1, 24, 24)
             result["check_nerr_vs_fp64_oracle"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+        if world == 1 and not args.no_extras and not deep and n_sl >= 1:
+            result["extra"] = extras(model, lib, h, _lib, d_img, d_tiles, d_recons, args.streams)
         if world == 1 and not args.no_cpu_baseline and not deep:
             result["cpu_baseline"] = cpu_baseline(sd, d_tiles.numpy()[:400], args.activation, args.cpu_seconds)
         else:
@@ -317,9 +442,44 @@ def main():
         info = model.device_info()
         result["device"] = info["name"]
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.barrier()
+    group.destroy()
+
+
+def extras(model, lib, h, _lib, d_img, d_tiles, d_recons, streams, budget_s=0.5):
+    """Rates of the two regions either side of the metric's, measured in this process after the timed region on ONE
+    slice (never `value`):
+      host_to_host_mpixel_s   numpy tiles on the host -> numpy (400,24,24) on the host through msiren_forward_tiles:
+                              SURVEY.md §8(d)'s drop-in call, PCIe copies included (error.py:233-258 is the region);
+      reconstruct_mpixel_s    slice -> tiles -> black filter -> forward -> weighted fold -> slice, device-resident
+                              (msiren_reconstruct_slices_dev): "pixels reconstructed" in the literal sense."""
+    tiles = d_tiles.numpy()[:400]
+    model(tiles)  # workspaces
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        model(tiles)
+        n += 1
+    h2h = n * 320 * 320 / (time.perf_counter() - t0) / 1e6
+    _lib.check(lib.msiren_set_streams(h, streams))
+    k = [0]
+
+    def rstep():
+        _lib.check(lib.msiren_reconstruct_slices_dev(h, d_img.ptr, 1, 320, 320, d_recons[k[0] & 1].ptr))
+        k[0] += 1
+
+    for _ in range(20):
+        rstep()
+    model.sync()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for _ in range(50):
+            rstep()
+        model.sync()
+        n += 50
+    rec = n * 320 * 320 / (time.perf_counter() - t0) / 1e6
+    return {"host_to_host_mpixel_s": h2h, "reconstruct_mpixel_s": rec,
+            "note": "one 320x320 slice per call, after the timed region: host numpy -> host numpy through "
+                    "msiren_forward_tiles (PCIe-inclusive), and the device-resident slice -> slice pipeline"}
 
 
 if __name__ == "__main__":

@@ -54,7 +54,8 @@ enum {
     MSIREN_PREC_BF16 = 1, /* bf16 operands, fp32 accumulate: register-resident single-product trunk,
                              dim_hidden = 512, num_layers <= 12 (BASELINE config 5; own tolerance)  */
     MSIREN_PREC_F16X3 = 2, /* split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate;
-                             fp32-equivalent accuracy (22-bit operands); H = 256, 2 <= L <= 17.
+                             fp32-equivalent accuracy (22-bit operands); H = 256, 2 <= L <= 11 (the
+                             per-layer tables must fit the 160 KB LDS beside the weight ring).
                              Other shapes silently use MSIREN_PREC_F32.                          */
     MSIREN_PREC_F16 = 3   /* as BF16 with fp16 operands (11-bit significand)                        */
 };
@@ -108,6 +109,9 @@ MSIREN_API const char* msiren_last_error(void);
  * (MSIREN_E_SHAPE otherwise, like load_state_dict's size-mismatch error); unknown names are
  * MSIREN_E_INVALID ("unexpected key").  Data is copied; the caller keeps ownership. */
 MSIREN_API int msiren_set_tensor(msiren_handle h, const char* name, const float* host_data, size_t n);
+/* state_dict()[name]: copies the tensor the handle holds (set by msiren_set_tensor, or received by
+ * msiren_broadcast_weights) into host_out; n must be its element count.  MSIREN_E_STATE if absent. */
+MSIREN_API int msiren_get_tensor(msiren_handle h, const char* name, float* host_out, size_t n);
 
 /* Packs the tensors into the kernels' layouts and uploads them.  Fails with MSIREN_E_STATE and a
  * list of missing keys if the trunk ("net.*") is incomplete; modulator / encoder keys are only
@@ -160,6 +164,35 @@ MSIREN_API int msiren_set_streams(msiren_handle h, int32_t n);
 /* Blocks until everything enqueued on the handle's streams has finished (the reference's implicit
  * synchronisation at .cpu(), error.py:256-258). */
 MSIREN_API int msiren_sync(msiren_handle h);
+
+/* ---- multi-GPU: weights replicated by ONE RCCL broadcast, patches sharded by the caller ------------
+ *
+ * The reference is single-process, single-GPU (practical_slurm_launcher.sh:8-11, test_mod_siren.py:90-93);
+ * patches are independent given the weights, so the forward has no exchange step and the only
+ * collective of the scale-out is the broadcast of the state_dict from one rank at load time
+ * (load_state_dict, test_mod_siren.py:116-118, executed on one rank instead of all).  librccl is
+ * dlopen'ed by the first of these calls: a single-GPU host never loads it.
+ *
+ * One process per GPU:   rank 0: msiren_comm_unique_id(id) -> ship the 128 bytes to the other ranks
+ *                        all:    msiren_comm_init_rank(h, id, 128, nranks, rank)
+ *                        all:    msiren_broadcast_weights(h, root)      [collective; commits the weights]
+ * One process, n GPUs:   msiren_comm_init_all(handles, n); msiren_broadcast_weights_all(handles, n, root)
+ *
+ * msiren_broadcast_weights: the root must hold every tensor it wants replicated (msiren_set_tensor);
+ * the key set travels with the payload, the other ranks end up with exactly the root's tensors and
+ * every rank's weights are committed (as by msiren_commit_weights) when the call returns.
+ * msiren_comm_barrier / msiren_comm_allreduce_max_f64 are the two plumbing collectives a benchmark
+ * needs (barrier around the timed region, MAX of the per-rank times); both synchronise the host. */
+#define MSIREN_COMM_ID_BYTES 128
+MSIREN_API int msiren_comm_unique_id(void* id_out, size_t bytes);
+MSIREN_API int msiren_comm_init_rank(msiren_handle h, const void* id, size_t bytes, int32_t nranks, int32_t rank);
+MSIREN_API int msiren_comm_init_all(msiren_handle* handles, int32_t n);
+MSIREN_API int msiren_broadcast_weights(msiren_handle h, int32_t root);
+MSIREN_API int msiren_broadcast_weights_all(msiren_handle* handles, int32_t n, int32_t root);
+MSIREN_API int msiren_comm_barrier(msiren_handle h);
+MSIREN_API int msiren_comm_allreduce_max_f64(msiren_handle h, double* inout, int32_t n);
+MSIREN_API int msiren_comm_info(msiren_handle h, int32_t* nranks, int32_t* rank);
+MSIREN_API int msiren_comm_destroy(msiren_handle h);
 
 /* ---- device memory + timing helpers (so that a host needs no other GPU runtime) --------------- */
 

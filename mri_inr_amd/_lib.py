@@ -21,6 +21,7 @@ ABI_VERSION = 1
 ACT_SINE, ACT_MORLET = 0, 1
 PREC_F32, PREC_BF16, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
 E_INVALID, E_STATE, E_SHAPE, E_HIP, E_NOMEM = -1, -2, -3, -4, -5
+COMM_ID_BYTES = 128
 
 
 class MsirenConfig(C.Structure):
@@ -58,6 +59,7 @@ PROTOTYPES = {
     "msiren_create": (C.c_int, [C.POINTER(MsirenConfig), C.POINTER(_vp)]),
     "msiren_destroy": (C.c_int, [_vp]),
     "msiren_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t]),
+    "msiren_get_tensor": (C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t]),
     "msiren_commit_weights": (C.c_int, [_vp]),
     "msiren_forward_mods": (C.c_int, [_vp, _vp, _i64, _vp]),
     "msiren_forward_mods_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
@@ -82,6 +84,15 @@ PROTOTYPES = {
     "msiren_profile_read": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "msiren_device_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_uint64)]),
     "msiren_flops_per_coord": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "msiren_comm_unique_id": (C.c_int, [_vp, C.c_size_t]),
+    "msiren_comm_init_rank": (C.c_int, [_vp, _vp, C.c_size_t, _i32, _i32]),
+    "msiren_comm_init_all": (C.c_int, [C.POINTER(_vp), _i32]),
+    "msiren_broadcast_weights": (C.c_int, [_vp, _i32]),
+    "msiren_broadcast_weights_all": (C.c_int, [C.POINTER(_vp), _i32, _i32]),
+    "msiren_comm_barrier": (C.c_int, [_vp]),
+    "msiren_comm_allreduce_max_f64": (C.c_int, [_vp, C.POINTER(C.c_double), _i32]),
+    "msiren_comm_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "msiren_comm_destroy": (C.c_int, [_vp]),
     "msiren_trunk_timeline": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "msiren_f16x3_timeline": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
 }

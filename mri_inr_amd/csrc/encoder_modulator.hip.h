@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void modulator_layer_kernel(ModulatorLayerPara
         const int b = b0 + r, fo = blockIdx.y * 64 + ff;
         if (b < nrows && fo < p.H) {
             const float s = red[0][r][ff] + red[1][r][ff] + red[2][r][ff] + red[3][r][ff] + p.bias[fo];
-            p.out[(size_t)b * p.H + fo] = s > 0.f ? s : 0.f;
+            p.out[(size_t)b * p.H + fo] = s <= 0.f ? 0.f : s;  // NaN stays NaN, as torch.relu
         }
     }
 }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void modulator_layer_mfma_kernel(ModulatorMfma
     if (r0 + rr < nrows) {
         const float s = red[0][rr][cc] + red[1][rr][cc] + red[2][rr][cc] + red[3][rr][cc] + p.bias[f0 + cc];
         const float neg = p.act == LIN_ACT_RELU ? 0.f : (p.act == LIN_ACT_LEAKY02 ? 0.2f * s : s);
-        p.out[(size_t)(r0 + rr) * p.H + f0 + cc] = s > 0.f ? s : neg;
+        p.out[(size_t)(r0 + rr) * p.H + f0 + cc] = s <= 0.f ? neg : s;  // NaN stays NaN, as torch's activations
     }
 }
 

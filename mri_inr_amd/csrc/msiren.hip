@@ -6,18 +6,23 @@
 //     [tiling] -> encoder -> modulator -> fused SIREN trunk -> [weighted fold]
 // Nothing here falls back to the CPU: every forward entry point launches HIP kernels or fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: librccl is dlopen'ed by the first msiren_comm_* call
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/msiren.h"
 #include "encoder_modulator.hip.h"
+#include "pass_queue.h"
 #include "siren_trunk_f16x3.hip.h"
 #include "siren_trunk_f32.hip.h"
 #include "siren_trunk_x1.hip.h"
@@ -60,7 +65,7 @@ struct msiren_ctx {
     struct StreamCtx {
         hipStream_t s = nullptr;
         DevBuf mods, modpad, latent, patches, keep, rec, queue, feat, plan;
-        unsigned queue_base = 0;  // value of the pass counter when the next launch starts
+        msiren::PassQueue pq;  // host view of the never-reset pass counter (pass_queue.h)
     } sc[2];
     int cur = 0, nstreams = 1;
     bool overlap = false;  // a host-pointer call is pipelining itself over both streams
@@ -68,6 +73,7 @@ struct msiren_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, std::vector<float>> tensors;  // state_dict, host copies
     std::map<std::string, size_t> expected;             // key -> element count
+    std::vector<float> grid_host;                       // the coordinate grid in effect (state_dict's, or rebuilt)
     bool committed = false, have_modulator = false, have_encoder = false;
     // trunk
     float *d_grid = nullptr, *d_l0 = nullptr, *d_wp = nullptr, *d_bias = nullptr, *d_wout = nullptr;
@@ -83,6 +89,7 @@ struct msiren_ctx {
     float winvx1[64] = {0};
     bool x1_ready = false;
     int num_cus = 256;
+    int lds_attr_f16[2][2] = {};  // dynamic-LDS limit already raised for siren_trunk_f16x3_kernel<act, R> ([R == 4][act])
     // modulator: transposed weights so that consecutive threads read consecutive outputs
     float *d_modw = nullptr, *d_modb = nullptr, *d_modw_rm = nullptr;  // transposed / as stored (row-major)
     // encoder
@@ -97,6 +104,10 @@ struct msiren_ctx {
     double prof_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
+    // multi-GPU: RCCL communicator this handle is a rank of (msiren_comm_*), staging buffer of its collectives
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_n = 1;
+    DevBuf ws_comm;
 };
 
 namespace {
@@ -180,10 +191,10 @@ int pack_trunk(msiren_ctx* h) {
     if (!missing.empty())
         return fail(MSIREN_E_STATE, "Missing key(s) in state_dict: %s", missing.c_str());
 
-    std::vector<float> grid;
+    std::vector<float>& grid = h->grid_host;  // the layer-0 tables of the 16-bit trunks are built from it as well
     if (const auto* g = get(h, "grid")) {
         grid = *g;
-    } else {  // the reference registers it as a buffer; rebuild it if a checkpoint lacks it
+    } else {  // the reference registers it as a buffer (modulated_siren.py:427-433); rebuild it if a checkpoint lacks it
         grid.resize((size_t)h->P * 2);
         const int S = h->S;
         std::vector<float> lin(S);
@@ -258,7 +269,7 @@ float f16_to_f32(uint16_t u) {
 int pack_trunk_f16x3(msiren_ctx* h) {
     h->f16x3_ready = false;
     const int H = h->H, L = h->L;
-    if (H != 256 || L < 2 || L > 17) return 0;
+    if (h->cfg.precision != MSIREN_PREC_F16X3 || H != 256 || L < 2 || msiren::F16Lds<3>::total(L) > 160 * 1024) return 0;
     const double two_pi = 6.283185307179586476925286766559;
     const double c = (double)h->cfg.w0 / two_pi;
     std::vector<uint16_t> wp((size_t)(L - 1) * 8 * 16 * 2 * 64 * 8);
@@ -300,8 +311,7 @@ int pack_trunk_f16x3(msiren_ctx* h) {
     {   // layer-0 activation table S0T[f/4][p][f%4] = act0(w0_initial * (W0 x_p + b0)), fp64 -> fp32
         const auto& W0 = *get(h, "net.layers.0.weight");
         const auto* B0 = h->cfg.use_bias ? get(h, "net.layers.0.bias") : nullptr;
-        std::vector<float> grid;
-        if (const auto* g = get(h, "grid")) grid = *g;
+        const std::vector<float>& grid = h->grid_host;  // pack_trunk ran first
         if (grid.size() != (size_t)h->P * 2) return fail(MSIREN_E_STATE, "grid buffer missing");
         std::vector<float> tab((size_t)64 * h->P * 4);
         const bool morlet = h->cfg.activation == MSIREN_ACT_MORLET;
@@ -372,8 +382,8 @@ int pack_trunk_x1(msiren_ctx* h) {
         l0last[i * 4 + 1] = (float)((double)W0[(size_t)f * 2 + 1] * c0);
         l0last[i * 4 + 2] = B0 ? (float)((double)(*B0)[f] * c0) : 0.f;
     }
-    const auto* g = get(h, "grid");
-    if (!g || g->size() != (size_t)h->P * 2) return fail(MSIREN_E_STATE, "grid buffer missing");
+    const std::vector<float>* g = &h->grid_host;  // pack_trunk ran first
+    if (g->size() != (size_t)h->P * 2) return fail(MSIREN_E_STATE, "grid buffer missing");
     std::vector<float> tab((size_t)128 * h->P * 4);
     const bool morlet = h->cfg.activation == MSIREN_ACT_MORLET;
     for (int f = 0; f < 512; ++f)
@@ -549,7 +559,8 @@ msiren::TrunkParams make_trunk_params(msiren_ctx* h, const float* mods, int stri
 
 // Pass queue of the persistent trunks.  Workgroup g starts with pass g; every executed pass performs exactly
 // one atomicAdd on the counter, so a launch of n passes advances it by n: the counter is never reset, the
-// host hands each launch the value it will find (no memset node per call).
+// host hands each launch the value it will find (no memset node per call).  The host value moves only once
+// the launch has been accepted (queue_launched); a failure in between leaves it where the device counter is.
 int queue_for_launch(msiren_ctx* h, int64_t npasses, int** counter, unsigned* base) {
     auto& c = h->sc[h->cur];
     if (!c.queue.p) {
@@ -559,12 +570,17 @@ int queue_for_launch(msiren_ctx* h, int64_t npasses, int** counter, unsigned* ba
         unsigned start = 0;
         if (const char* e = std::getenv("MSIREN_QUEUE_START")) start = (unsigned)std::strtoul(e, nullptr, 0);
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c.queue.p, (int)start, 64, c.s));
-        c.queue_base = start;
+        c.pq.reset(start);
     }
     *counter = (int*)c.queue.p;
-    *base = c.queue_base;
-    c.queue_base += (unsigned)npasses;
+    *base = c.pq.begin(npasses);
     return 0;
+}
+
+int queue_launched(msiren_ctx* h, int rc) {
+    if (rc == 0) h->sc[h->cur].pq.commit();
+    else h->sc[h->cur].pq.abort();
+    return rc;
 }
 
 // After a launch whose number of passes only the device knows (black patches skipped): reset the counter.
@@ -572,7 +588,7 @@ int queue_reset_after_plan_launch(msiren_ctx* h) {
     auto& c = h->sc[h->cur];
     if (!c.queue.p) return 0;
     HIPCHK(hipMemsetAsync(c.queue.p, 0, 4, c.s));
-    c.queue_base = 0;
+    c.pq.reset(0);
     return 0;
 }
 
@@ -581,14 +597,16 @@ int launch_trunk_f16x3_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int gri
     const int lds = msiren::F16Lds<R>::total(h->L);
     auto k0 = msiren::siren_trunk_f16x3_kernel<0, R>;
     auto k1 = msiren::siren_trunk_f16x3_kernel<1, R>;
-    const void* kp = h->cfg.activation == MSIREN_ACT_MORLET ? (const void*)k1 : (const void*)k0;
-    static int lds_set[64][2] = {};  // per device, template instantiation (R) and activation: raise the limit once
-    int& done = lds_set[h->cfg.device & 63][h->cfg.activation == MSIREN_ACT_MORLET ? 1 : 0];
+    const bool mor = h->cfg.activation == MSIREN_ACT_MORLET;
+    const void* kp = mor ? (const void*)k1 : (const void*)k0;
+    // raise the dynamic-LDS limit once per handle and kernel instance (R, activation): handle-local state, so
+    // handles on different threads never share it
+    int& done = h->lds_attr_f16[R == 4 ? 1 : 0][mor ? 1 : 0];
     if (done < lds) {
         HIPCHK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         done = lds;
     }
-    if (h->cfg.activation == MSIREN_ACT_MORLET)
+    if (mor)
         hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
     else
         hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
@@ -628,9 +646,11 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     // call (other stream) to run beside the persistent trunk workgroup; R = 4 fills the CU.
     int ring = (h->nstreams > 1 || h->overlap) ? 3 : 4;
     if (const char* e = std::getenv("MSIREN_F16_RING")) ring = std::atoi(e);
-    if (ring >= 4 && msiren::F16Lds<4>::total(h->L) <= 160 * 1024) return launch_trunk_f16x3_r<4>(h, p, grid);
-    return launch_trunk_f16x3_r<3>(h, p, grid);
+    if (ring >= 4 && msiren::F16Lds<4>::total(h->L) <= 160 * 1024) return queue_launched(h, launch_trunk_f16x3_r<4>(h, p, grid));
+    return queue_launched(h, launch_trunk_f16x3_r<3>(h, p, grid));
 }
+
+int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int grid);
 
 int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     msiren::TrunkX1Params p{};
@@ -657,6 +677,10 @@ int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_
     const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
     int rc = queue_for_launch(h, (units + 3) / 4, &p.pass_counter, &p.pass_base);
     if (rc) return rc;
+    return queue_launched(h, launch_trunk_x1_kernel(h, p, grid));
+}
+
+int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int grid) {
     const int lds = msiren::X1Lds<3>::total(h->L);
     const bool bf = h->cfg.precision == MSIREN_PREC_BF16, mor = h->cfg.activation == MSIREN_ACT_MORLET, res = h->cfg.residual != 0;
 #define MSIREN_X1_LAUNCH(BF, A, RS)                                                                  \
@@ -871,6 +895,108 @@ int check(msiren_ctx* h, bool need_commit = true) {
     return use_device(h);
 }
 
+
+// ---- RCCL (dlopen'ed on first use; types from <rccl/rccl.h>) -----------------------------------------
+struct Rccl {
+    void* dl = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {std::getenv("MSIREN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            r.dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.dl) break;
+            r.err = dlerror();
+        }
+        if (!r.dl) return;
+        bool ok = true;
+        auto sym = [&](const char* n) {
+            void* p = dlsym(r.dl, n);
+            if (!p) {
+                ok = false;
+                r.err = std::string("missing symbol ") + n;
+            }
+            return p;
+        };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        if (!ok) {
+            dlclose(r.dl);
+            r.dl = nullptr;
+        }
+    });
+    return r.dl ? &r : nullptr;
+}
+
+int need_rccl(Rccl** out) {
+    Rccl* r = rccl();
+    if (!r) {
+        return fail(MSIREN_E_STATE, "librccl could not be loaded (multi-GPU entry points need it; set MSIREN_RCCL_LIB to its path)");
+    }
+    *out = r;
+    return 0;
+}
+
+#define NCCLCHK(r_, expr)                                                                         \
+    do {                                                                                          \
+        ncclResult_t e_ = (expr);                                                                 \
+        if (e_ != ncclSuccess)                                                                    \
+            return fail(MSIREN_E_HIP, "%s failed: %s (%s:%d)", #expr, (r_)->GetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// Flat image of the state_dict for the broadcast: [one presence flag per expected key][every expected tensor],
+// keys in the (sorted) order of `expected`; absent tensors travel as zeros and stay absent on the receivers.
+size_t bcast_elems(msiren_ctx* h) {
+    size_t n = h->expected.size();
+    for (auto& kv : h->expected) n += kv.second;
+    return n;
+}
+
+void bcast_pack(msiren_ctx* h, std::vector<float>& flat) {
+    flat.assign(bcast_elems(h), 0.f);
+    size_t i = 0, off = h->expected.size();
+    for (auto& kv : h->expected) {
+        auto it = h->tensors.find(kv.first);
+        if (it != h->tensors.end()) {
+            flat[i] = 1.f;
+            std::copy(it->second.begin(), it->second.end(), flat.begin() + off);
+        }
+        ++i;
+        off += kv.second;
+    }
+}
+
+void bcast_unpack(msiren_ctx* h, const std::vector<float>& flat) {
+    size_t i = 0, off = h->expected.size();
+    h->tensors.clear();
+    for (auto& kv : h->expected) {
+        if (flat[i] != 0.f) h->tensors[kv.first].assign(flat.begin() + off, flat.begin() + off + kv.second);
+        ++i;
+        off += kv.second;
+    }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -941,6 +1067,8 @@ int msiren_destroy(msiren_handle h) {
     (void)hipSetDevice(h->cfg.device);
     for (auto& c : h->sc)
         if (c.s) (void)hipStreamSynchronize(c.s);
+    if (h->comm) (void)msiren_comm_destroy(h);
+    if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
     if (h->d_wp16) (void)hipFree(h->d_wp16);
     for (void* q : {h->d_wpx1, h->d_biasx1, h->d_woutx1})
         if (q) (void)hipFree(q);
@@ -972,6 +1100,17 @@ int msiren_set_tensor(msiren_handle h, const char* name, const float* host_data,
         return fail(MSIREN_E_SHAPE, "size mismatch for %s: got %zu elements, the configuration implies %zu", name, n, it->second);
     h->tensors[name].assign(host_data, host_data + n);
     h->committed = false;
+    return 0;
+}
+
+int msiren_get_tensor(msiren_handle h, const char* name, float* host_out, size_t n) {
+    if (!h || !name || (!host_out && n)) return fail(MSIREN_E_INVALID, "null argument");
+    auto ex = h->expected.find(name);
+    if (ex == h->expected.end()) return fail(MSIREN_E_INVALID, "Unexpected key in state_dict: \"%s\"", name);
+    auto it = h->tensors.find(name);
+    if (it == h->tensors.end()) return fail(MSIREN_E_STATE, "tensor %s has not been set", name);
+    if (it->second.size() != n) return fail(MSIREN_E_SHAPE, "size mismatch for %s: asked for %zu elements, it has %zu", name, n, it->second.size());
+    std::copy(it->second.begin(), it->second.end(), host_out);
     return 0;
 }
 
@@ -1362,6 +1501,161 @@ int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, flo
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipFree(st.p));
     HIPCHK(hipFree(q.p));
+    return 0;
+}
+
+// ---- multi-GPU (include/msiren.h, "multi-GPU") ---------------------------------------------------------
+int msiren_comm_unique_id(void* id_out, size_t bytes) {
+    Rccl* r;
+    int rc = need_rccl(&r);
+    if (rc) return rc;
+    if (!id_out || bytes < sizeof(ncclUniqueId)) return fail(MSIREN_E_INVALID, "id buffer must hold %zu bytes", sizeof(ncclUniqueId));
+    ncclUniqueId id;
+    NCCLCHK(r, r->GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+int msiren_comm_init_rank(msiren_handle h, const void* id, size_t bytes, int32_t nranks, int32_t rank) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    Rccl* r;
+    if ((rc = need_rccl(&r))) return rc;
+    if (!id || bytes < sizeof(ncclUniqueId)) return fail(MSIREN_E_INVALID, "id must be the %zu bytes of msiren_comm_unique_id", sizeof(ncclUniqueId));
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(MSIREN_E_INVALID, "bad rank %d of %d", rank, nranks);
+    if (h->comm) return fail(MSIREN_E_STATE, "the handle already belongs to a communicator (msiren_comm_destroy first)");
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    NCCLCHK(r, r->CommInitRank(&h->comm, nranks, uid, rank));
+    h->comm_n = nranks;
+    h->comm_rank = rank;
+    return 0;
+}
+
+int msiren_comm_init_all(msiren_handle* hs, int32_t n) {
+    if (!hs || n < 1) return fail(MSIREN_E_INVALID, "bad arguments");
+    Rccl* r;
+    int rc = need_rccl(&r);
+    if (rc) return rc;
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i]) return fail(MSIREN_E_INVALID, "null handle %d", i);
+        if (hs[i]->comm) return fail(MSIREN_E_STATE, "handle %d already belongs to a communicator", i);
+        devs[i] = hs[i]->cfg.device;
+        for (int j = 0; j < i; ++j)
+            if (devs[j] == devs[i]) return fail(MSIREN_E_INVALID, "handles %d and %d share device %d: one rank per GPU", j, i, devs[i]);
+    }
+    std::vector<ncclComm_t> comms(n);
+    NCCLCHK(r, r->CommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) {
+        hs[i]->comm = comms[i];
+        hs[i]->comm_n = n;
+        hs[i]->comm_rank = i;
+    }
+    return 0;
+}
+
+static int broadcast_weights_group(msiren_handle* hs, int n, int32_t root) {
+    Rccl* r;
+    int rc = need_rccl(&r);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        if ((rc = check(hs[i], false))) return rc;
+        if (!hs[i]->comm) return fail(MSIREN_E_STATE, "no communicator: call msiren_comm_init_rank / msiren_comm_init_all first");
+        if (root < 0 || root >= hs[i]->comm_n) return fail(MSIREN_E_INVALID, "root %d out of range (%d ranks)", root, hs[i]->comm_n);
+    }
+    // every rank derives the layout from its own configuration: it must be the same model everywhere
+    const size_t elems = bcast_elems(hs[0]);
+    std::vector<float> flat;
+    for (int i = 0; i < n; ++i) {
+        msiren_ctx* h = hs[i];
+        if (bcast_elems(h) != elems) return fail(MSIREN_E_SHAPE, "handles of one communicator describe different models");
+        HIPCHK(hipSetDevice(h->cfg.device));
+        if ((rc = sync_all(h)) || (rc = ensure(h, h->ws_comm, elems * sizeof(float)))) return rc;
+        if (h->comm_rank == root) {
+            bcast_pack(h, flat);
+            HIPCHK(hipMemcpyAsync(h->ws_comm.p, flat.data(), elems * sizeof(float), hipMemcpyHostToDevice, h->sc[0].s));
+            HIPCHK(hipStreamSynchronize(h->sc[0].s));  // `flat` is reused below
+        }
+    }
+    if (n > 1) NCCLCHK(r, r->GroupStart());
+    for (int i = 0; i < n; ++i) {
+        msiren_ctx* h = hs[i];
+        HIPCHK(hipSetDevice(h->cfg.device));
+        NCCLCHK(r, r->Broadcast(h->ws_comm.p, h->ws_comm.p, elems, ncclFloat32, root, h->comm, h->sc[0].s));
+    }
+    if (n > 1) NCCLCHK(r, r->GroupEnd());
+    for (int i = 0; i < n; ++i) {
+        msiren_ctx* h = hs[i];
+        HIPCHK(hipSetDevice(h->cfg.device));
+        if (h->comm_rank != root) {
+            flat.resize(elems);
+            HIPCHK(hipMemcpyAsync(flat.data(), h->ws_comm.p, elems * sizeof(float), hipMemcpyDeviceToHost, h->sc[0].s));
+            HIPCHK(hipStreamSynchronize(h->sc[0].s));
+            bcast_unpack(h, flat);
+        } else {
+            HIPCHK(hipStreamSynchronize(h->sc[0].s));
+        }
+        if ((rc = msiren_commit_weights(h))) return rc;
+    }
+    return 0;
+}
+
+int msiren_broadcast_weights(msiren_handle h, int32_t root) {
+    if (!h) return fail(MSIREN_E_INVALID, "null handle");
+    return broadcast_weights_group(&h, 1, root);
+}
+
+int msiren_broadcast_weights_all(msiren_handle* hs, int32_t n, int32_t root) {
+    if (!hs || n < 1) return fail(MSIREN_E_INVALID, "bad arguments");
+    for (int i = 0; i < n; ++i)
+        if (!hs[i]) return fail(MSIREN_E_INVALID, "null handle %d", i);
+    return broadcast_weights_group(hs, n, root);
+}
+
+int msiren_comm_allreduce_max_f64(msiren_handle h, double* inout, int32_t n) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !inout)) return fail(MSIREN_E_INVALID, "bad arguments");
+    if ((rc = sync_all(h))) return rc;
+    if (!h->comm || n == 0) return 0;  // a communicator of one: the maximum is the input
+    Rccl* r;
+    if ((rc = need_rccl(&r))) return rc;
+    if ((rc = ensure(h, h->ws_comm, (size_t)n * sizeof(double)))) return rc;
+    HIPCHK(hipMemcpyAsync(h->ws_comm.p, inout, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->sc[0].s));
+    NCCLCHK(r, r->AllReduce(h->ws_comm.p, h->ws_comm.p, (size_t)n, ncclFloat64, ncclMax, h->comm, h->sc[0].s));
+    HIPCHK(hipMemcpyAsync(inout, h->ws_comm.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->sc[0].s));
+    HIPCHK(hipStreamSynchronize(h->sc[0].s));
+    return 0;
+}
+
+int msiren_comm_barrier(msiren_handle h) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (!h->comm) return sync_all(h);  // a communicator of one
+    double token = 0.0;
+    return msiren_comm_allreduce_max_f64(h, &token, 1);
+}
+
+int msiren_comm_info(msiren_handle h, int32_t* nranks, int32_t* rank) {
+    if (!h) return fail(MSIREN_E_INVALID, "null handle");
+    if (nranks) *nranks = h->comm ? h->comm_n : 1;
+    if (rank) *rank = h->comm ? h->comm_rank : 0;
+    return 0;
+}
+
+int msiren_comm_destroy(msiren_handle h) {
+    if (!h) return fail(MSIREN_E_INVALID, "null handle");
+    if (!h->comm) return 0;
+    Rccl* r;
+    int rc = need_rccl(&r);
+    if (rc) return rc;
+    (void)hipSetDevice(h->cfg.device);
+    (void)sync_all(h);
+    NCCLCHK(r, r->CommDestroy(h->comm));
+    h->comm = nullptr;
+    h->comm_n = 1;
+    h->comm_rank = 0;
     return 0;
 }
 

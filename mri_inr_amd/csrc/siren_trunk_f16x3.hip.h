@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
     };
     // the kept patches only: known on the device (scalar: a vector register here costs the co-residency of §4.3)
     const int total_units = __builtin_amdgcn_readfirstlane(p.plan ? p.plan[1] : p.total_units);
-    if (cur_pass * 4 >= total_units) return;
+    // unsigned compare: a pass id that came out negative (host/device counter disagreement) ends the workgroup
+    // instead of indexing out of bounds
+    const unsigned npasses = (unsigned)(total_units + 3) >> 2;
+    if ((unsigned)cur_pass >= npasses) return;
 #pragma unroll
     for (int s = 0; s < R - 1; ++s) dma_next();
 
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Param
         wf_[0][3] = r0[3 * 64];
     }
 
-    for (int pass = 0; cur_pass * 4 < total_units; ++pass) {
+    for (int pass = 0; (unsigned)cur_pass < npasses; ++pass) {
         auto stamp = [&](int i) {
             if constexpr (DBG) {
                 const unsigned long long t = i == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();

@@ -10,6 +10,9 @@ The reference is single-process; this is the scale-out the nor
 
 from __future__ import annotations
 
+import ctypes as C
+import os
+
 import numpy as np
 
 
@@ -88,3 +91,62 @@ def sharded_forward(model, tiles: np.ndarray, group=None, gather: bool = True):
     if not gather:
         return local, (lo, hi)
     return gather_outputs(local, tiles.shape[0], 0, group)
+
+
+# ---- torch-free path: RCCL through the C ABI (include/msiren.h, "multi-GPU") -----------------------------------
+
+class RcclGroup:
+    """This process's rank in an RCCL communicator owned by ``libmsiren`` -- no torch.distributed, one HIP runtime.
+
+    ``RcclGroup(model)`` reads RANK / WORLD_SIZE / MASTER_* (torchrun's contract, also what
+    :func:`mri_inr_amd.launch.spawn_ranks` sets), ships rank 0's 128-byte unique id to the other ranks
+    (:func:`mri_inr_amd.launch.exchange_from_rank0`) and joins the communicator with the model's handle.
+    With WORLD_SIZE == 1 (or unset) nothing is initialised and every collective is the identity.
+    """
+
+    def __init__(self, model, env=None):
+        from . import _lib
+        from .launch import exchange_from_rank0
+
+        env = os.environ if env is None else env
+        self.rank, self.world = int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1"))
+        self.model = model
+        model._ensure_handle()
+        self._lib, self._h = model._lib, model._h
+        if self.world > 1:
+            uid = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            if self.rank == 0:
+                _lib.check(self._lib.msiren_comm_unique_id(uid, _lib.COMM_ID_BYTES))
+            blob = exchange_from_rank0(bytes(uid.raw) if self.rank == 0 else None, env=env)
+            _lib.check(self._lib.msiren_comm_init_rank(self._h, blob, len(blob), self.world, self.rank))
+
+    def broadcast_weights(self, src: int = 0):
+        """load_state_dict on ``src`` only; every rank ends up with its weights, committed."""
+        from . import _lib
+
+        if self.rank == src:
+            self.model._push_tensors()
+        if self.world == 1:
+            self.model._ensure_committed()
+            return
+        _lib.check(self._lib.msiren_broadcast_weights(self._h, src))
+        self.model._committed = True
+        if self.rank != src:
+            self.model._pull_tensors()  # keep state_dict() in step with what the device now holds
+
+    def barrier(self):
+        from . import _lib
+
+        _lib.check(self._lib.msiren_comm_barrier(self._h))
+
+    def max(self, value: float) -> float:
+        from . import _lib
+
+        v = (C.c_double * 1)(float(value))
+        _lib.check(self._lib.msiren_comm_allreduce_max_f64(self._h, v, 1))
+        return float(v[0])
+
+    def destroy(self):
+        from . import _lib
+
+        _lib.check(self._lib.msiren_comm_destroy(self._h))

@@ -162,7 +162,7 @@ class ModulatedSiren:
         cfg.siren_patch_size = self.siren_patch_size
         cfg.residual = int(self.residual)
         # "auto": the split-fp16 trunk (fp32-equivalent accuracy, ~3x faster) wherever the library supports the
-        # shape (H = 256, 2 <= L <= 12, no residual); the library itself falls back to the fp32 trunk otherwise
+        # shape (H = 256, 2 <= L <= 11, no residual); the library itself falls back to the fp32 trunk otherwise
         cfg.precision = {"auto": _lib.PREC_F16X3, "fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "f16x3": _lib.PREC_F16X3,
                          "f16": _lib.PREC_F16, "fp16": _lib.PREC_F16}[self.precision]
         cfg.device = int(self._device or 0)
@@ -180,13 +180,31 @@ class ModulatedSiren:
         self._h = h
         self._committed = False
 
+    def _push_tensors(self):
+        """msiren_set_tensor for every entry of the state_dict (no commit)."""
+        self._ensure_handle()
+        for k, v in self._sd.items():
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            _lib.check(self._lib.msiren_set_tensor(self._h, k.encode(), a.ctypes.data, a.size))
+        self._committed = False
+
+    def _pull_tensors(self):
+        """Refresh the host mirror from the tensors the handle holds (after msiren_broadcast_weights)."""
+        self._ensure_handle()
+        for k, v in list(self._sd.items()):
+            a = np.empty(v.shape, dtype=np.float32)
+            rc = self._lib.msiren_get_tensor(self._h, k.encode(), a.ctypes.data, a.size)
+            if rc == _lib.E_STATE:  # the source rank did not hold it (e.g. no encoder)
+                continue
+            _lib.check(rc)
+            self._sd[k] = a
+        self.grid = self._sd["grid"]
+
     def _ensure_committed(self):
         self._ensure_handle()
         if self._committed:
             return
-        for k, v in self._sd.items():
-            a = np.ascontiguousarray(v, dtype=np.float32)
-            _lib.check(self._lib.msiren_set_tensor(self._h, k.encode(), a.ctypes.data, a.size))
+        self._push_tensors()
         _lib.check(self._lib.msiren_commit_weights(self._h))
         self._committed = True
 

@@ -1,0 +1,169 @@
+"""Multi-GPU plumbing on the one card of the GPU box: RCCL through the C ABI (include/msiren.h, "multi-GPU") with a
+communicator of one rank, and bench.py starting its own ranks (gloo lets two ranks share the card).  The 2-rank
+logic of partition / broadcast is covered on the CPU in test_dist_gloo.py and test_launch.py."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from mri_inr_amd import launch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, timeout=600, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in launch.ENV_KEYS}
+    e.update(env or {})
+    return subprocess.run([sys.executable, "-c", textwrap.dedent(script)], cwd=ROOT, env=e, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_rccl_through_the_c_abi_single_rank_torch_free():
+    """ncclGetUniqueId -> ncclCommInitRank -> ncclBroadcast of the state_dict blob -> commit -> forward, barrier and
+    MAX-reduce, all through libmsiren: no torch in the process, one HIP runtime."""
+    r = _run("""
+        import ctypes as C, sys, numpy as np
+        from mri_inr_amd import ModulatedSiren, _lib, synthetic as syn
+        from oracle import siren_oracle as orc
+        sd = syn.make_state_dict(seed=3, trained_like=True)
+        m = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
+                           use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                           outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda:0", activation="sine")
+        m._sd.update(sd)
+        lib, h = m._lib, m._h
+        uid = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(lib.msiren_comm_unique_id(uid, _lib.COMM_ID_BYTES))
+        assert any(uid.raw)
+        _lib.check(lib.msiren_comm_init_rank(h, uid.raw, _lib.COMM_ID_BYTES, 1, 0))
+        assert lib.msiren_comm_init_rank(h, uid.raw, _lib.COMM_ID_BYTES, 1, 0) == _lib.E_STATE   # already a member
+        n, r = C.c_int32(), C.c_int32()
+        _lib.check(lib.msiren_comm_info(h, C.byref(n), C.byref(r)))
+        assert (n.value, r.value) == (1, 0)
+        m._push_tensors()
+        _lib.check(lib.msiren_broadcast_weights(h, 0))          # collective; commits
+        assert lib.msiren_broadcast_weights(h, 1) == _lib.E_INVALID
+        m._committed = True
+        a = np.empty(sd["net.layers.1.weight"].shape, np.float32)
+        _lib.check(lib.msiren_get_tensor(h, b"net.layers.1.weight", a.ctypes.data, a.size))
+        assert np.array_equal(a, sd["net.layers.1.weight"])
+        tiles = np.random.default_rng(0).random((16, 32, 32), dtype=np.float32)
+        out = m(tiles)
+        ref = orc.modulated_siren_forward(sd, tiles, num_layers=5, dtype=np.float64)
+        err = float(np.abs(out - ref).max() / np.abs(ref).max())
+        v = (C.c_double * 2)(err, -1.0)
+        _lib.check(lib.msiren_comm_allreduce_max_f64(h, v, 2))
+        _lib.check(lib.msiren_comm_barrier(h))
+        assert (v[0], v[1]) == (err, -1.0)
+        _lib.check(lib.msiren_comm_destroy(h))
+        _lib.check(lib.msiren_comm_barrier(h))                  # a communicator of one again
+        assert "torch" not in sys.modules
+        print("NERR", err)
+        sys.exit(0 if err < 1e-4 else 1)
+    """)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "NERR" in r.stdout
+
+
+def test_rccl_group_object_and_comm_init_all():
+    """dist.RcclGroup (what bench.py uses) with WORLD_SIZE unset, and the one-process form
+    msiren_comm_init_all / msiren_broadcast_weights_all on the one device that is here."""
+    r = _run("""
+        import ctypes as C, sys, numpy as np
+        from mri_inr_amd import ModulatedSiren, _lib, synthetic as syn
+        from mri_inr_amd.dist import RcclGroup
+        sd = syn.make_state_dict(seed=5)
+        def model():
+            return ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
+                                  use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                                  outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda:0", activation="sine")
+        tiles = np.random.default_rng(0).random((5, 32, 32), dtype=np.float32)
+        ref = model(); ref.load_state_dict(sd); want = ref(tiles)
+        m = model(); g = RcclGroup(m); m._sd.update(sd); g.broadcast_weights(0); g.barrier()
+        assert g.max(3.5) == 3.5 and np.array_equal(m(tiles), want)
+        g.destroy()
+        m2 = model(); m2._sd.update(sd); m2._push_tensors()
+        hs = (C.c_void_p * 1)(m2._h)
+        _lib.check(m2._lib.msiren_comm_init_all(hs, 1))
+        _lib.check(m2._lib.msiren_broadcast_weights_all(hs, 1, 0))
+        m2._committed = True
+        assert np.array_equal(m2(tiles), want)
+        two = (C.c_void_p * 2)(m._h, m2._h)
+        assert m2._lib.msiren_comm_init_all(two, 2) in (_lib.E_INVALID, _lib.E_STATE)   # same device twice / already a member
+        assert "torch" not in sys.modules
+        print("OK")
+    """)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_commit_without_the_grid_buffer(prec):
+    """A C-ABI consumer may omit "grid" (the reference registers it as a buffer, modulated_siren.py:427-433): the
+    library rebuilds it, for every trunk -- same bits as with the buffer supplied."""
+    from mri_inr_amd import ModulatedSiren, _lib, synthetic as syn
+
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    kw = dict(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0, use_bias=True,
+              dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None, outer_patch_size=32, inner_patch_size=16,
+              siren_patch_size=24, device="cuda:0", activation="sine", precision=prec)
+    tiles = np.random.default_rng(1).random((7, 32, 32), dtype=np.float32)
+    a = ModulatedSiren(**kw)
+    a.load_state_dict(sd)
+    want = a.to("cuda:0")(tiles)
+    b = ModulatedSiren(**kw)
+    for k, v in sd.items():
+        if k != "grid":
+            v = np.ascontiguousarray(v, np.float32)
+            _lib.check(b._lib.msiren_set_tensor(b._h, k.encode(), v.ctypes.data, v.size))
+    _lib.check(b._lib.msiren_commit_weights(b._h))
+    b._committed = True
+    assert np.array_equal(b(tiles), want)
+
+
+def _bench(args, env=None, timeout=900):
+    e = {k: v for k, v in os.environ.items() if k not in launch.ENV_KEYS}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line_carries_roofline_cpu_baseline_and_extras():
+    d = _bench(["--steps", "20", "--warmup", "5", "--cpu-seconds", "2"])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["metric"] == "Mpixels/sec reconstructed (320x320 slice, hidden=256, 5 layers)"
+    assert "configs[1]" in d["config"]["workload"] and d["config"]["warmup_steps_run"] >= 5
+    assert abs(d["value"] - 320 * 320 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["launches"] >= 200 and 0.2 < rf["frac"] < 1.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    ex = d["extra"]
+    assert 0 < ex["host_to_host_mpixel_s"] < d["value"] * 1.05   # PCIe-inclusive: never faster than device-resident
+    assert ex["reconstruct_mpixel_s"] > 0
+
+
+def test_bench_gpus2_starts_its_own_ranks_gloo_rehearsal_on_one_card():
+    """`python bench.py --gpus 2` with no launcher: two ranks, n_gpus 2 in the line (weak: one slice per rank;
+    strong: a fixed batch of 6 slices split 3 + 3)."""
+    env = {"MSIREN_BENCH_BACKEND": "gloo"}
+    d = _bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"], env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["slices_per_step_total"] == 2
+    assert abs(d["value"] - 2 * 320 * 320 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+    s = _bench(["--gpus", "2", "--total-slices", "6", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"], env)
+    assert s["n_gpus"] == 2 and s["scaling"] == "strong"
+    assert s["config"]["slices_per_step_total"] == 6 and s["config"]["slices_per_step_rank0"] == 3
+    assert abs(s["value"] - 6 * 320 * 320 / s["ms_per_step"] / 1e3) < 1e-6 * s["value"]
+
+
+def test_bench_strong_scaling_config3_single_gpu():
+    d = _bench(["--total-slices", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["patches_per_step_rank0"] == 25600
+    assert "configs[2]" in d["config"]["workload"]

@@ -40,11 +40,17 @@ def check(out, ref, tol=TOL, rtol=RMS_TOL):
     return e
 
 
+PRECISIONS = ["fp32", "f16x3"]  # exact-fp32 MFMA trunk / split-fp16 trunk: every reference fixture meets both
+
+
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("act", ["sine", "morlet"])
-def test_trunk_vs_reference_fixtures(act):
+def test_trunk_vs_reference_fixtures(act, prec):
+    """SirenNet.forward (modulated_siren.py:215-233) at the YAML shape against the reference's outputs, on the
+    exact-fp32 kernel (siren_trunk_f32_kernel<256,...>) and on the split-fp16 kernel: same gate."""
     g = load_golden(f"trunk_{act}.npz")
     sd = syn.make_state_dict(seed=7)
-    m = make_model(sd, act=act)
+    m = make_model(sd, act=act, precision=prec)
     cases = {
         "uniform_B1": syn.make_mods(31, 5, 1, 256),
         "uniform_B64": syn.make_mods(32, 5, 64, 256),
@@ -66,18 +72,19 @@ def test_tiny_vs_reference_fixture(act):
     meta = json.loads(str(g["meta"]))
     sd = syn.make_state_dict(seed=meta["seed"], dim_hidden=meta["H"], num_layers=meta["L"],
                              latent_dim=meta["Z"], siren_patch_size=meta["S"])
-    m = make_model(sd, H=meta["H"], L=meta["L"], Z=meta["Z"], S=meta["S"], act=act)
+    m = make_model(sd, H=meta["H"], L=meta["L"], Z=meta["Z"], S=meta["S"], act=act, precision="fp32")  # H = 32: fp32 trunk
     mods = syn.make_mods(meta["mods_seed"], meta["L"], meta["B"], meta["H"])
     out = m.forward_mods(mods)
     check(out.reshape(meta["B"], -1), g["out"])
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("preset", ["default", "trained"])
 @pytest.mark.parametrize("act", ["sine", "morlet"])
-def test_forward_tiles_and_latent_vs_reference(preset, act):
+def test_forward_tiles_and_latent_vs_reference(preset, act, prec):
     g = load_golden(f"forward_{preset}_{act}.npz")
     sd = syn.make_state_dict(seed=7, trained_like=(preset == "trained"))
-    m = make_model(sd, act=act)
+    m = make_model(sd, act=act, precision=prec)
     tiles = np.random.default_rng(42).random((8, 32, 32), dtype=np.float32)
     out = m(tiles)
     check(out, g["out"])
@@ -87,10 +94,11 @@ def test_forward_tiles_and_latent_vs_reference(preset, act):
     check(out_m, g["out"])
 
 
-def test_slice_reconstruction_vs_reference():
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_slice_reconstruction_vs_reference(prec):
     g = load_golden("slice_recon.npz")
     sd = syn.make_state_dict(seed=7, trained_like=True)
-    m = make_model(sd)
+    m = make_model(sd, precision=prec)
     img = syn.make_slice(0, 160, 128, brain_mask=True)
     rec = m.reconstruct(img)
     check(rec, g["image"][0])
@@ -114,7 +122,8 @@ def test_trunk_vs_oracle_shapes(H, L, S, B, act, bias):
     sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
     m = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=256, w0=1.0, w0_initial=30.0,
                        use_bias=bias, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
-                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=S, device="cuda", activation=act)
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=S, device="cuda", activation=act,
+                       precision="fp32")
     m.load_state_dict(sd, strict=False)
     m.to("cuda")
     mods = syn.make_mods(5, L, B, H)
@@ -235,23 +244,6 @@ def test_modulator_kernels_vs_oracle(H, Z, L, B):
     check(out.reshape(B, -1), ref)
 
 
-@pytest.mark.parametrize("act", ["sine", "morlet"])
-def test_f16x3_trunk_vs_reference_fixtures(act):
-    """Split-fp16 trunk (3 x f16 MFMA per product, fp32 accumulate): same gate as the fp32 path."""
-    g = load_golden(f"trunk_{act}.npz")
-    sd = syn.make_state_dict(seed=7)
-    m = make_model(sd, act=act, precision="f16x3")
-    cases = {
-        "uniform_B1": syn.make_mods(31, 5, 1, 256),
-        "uniform_B64": syn.make_mods(32, 5, 64, 256),
-        "sparse_B16": syn.make_mods(33, 5, 16, 256, lo=0.0, hi=2.0, zero_fraction=0.5),
-        "modulator_B16": g["modulator_mods"],
-    }
-    for name, mods in cases.items():
-        out = m.forward_mods(mods)
-        check(out.reshape(out.shape[0], -1), g[name])
-
-
 @pytest.mark.parametrize("L,S,B", [(5, 24, 400), (5, 24, 7), (2, 24, 5), (3, 10, 9), (4, 24, 1030), (6, 8, 33), (8, 24, 50),
                                    (11, 24, 20)])
 def test_f16x3_trunk_vs_oracle_shapes(L, S, B):
@@ -278,8 +270,9 @@ def test_f16x3_trunk_vs_oracle_shapes(L, S, B):
 
 def test_f16x3_full_forward_matches_fp32_path():
     sd = syn.make_state_dict(seed=7, trained_like=True)
-    m32 = make_model(sd)
+    m32 = make_model(sd, precision="fp32")
     m16 = make_model(sd, precision="f16x3")
+    assert m32._config().precision != m16._config().precision
     tiles = np.random.default_rng(3).random((50, 32, 32), dtype=np.float32)
     a, b = m32(tiles), m16(tiles)
     ref = orc.modulated_siren_forward(sd, tiles, num_layers=5, dtype=np.float64)
@@ -674,10 +667,12 @@ def test_slice_pipeline_other_tiling_geometries(inner, S):
     assert nerr(d_o.numpy()[0], g[f"wfold_{inner}_{S}"]) < 2e-6
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("name", ["w0", "nobias", "small", "morlet_w0", "deep"])
-def test_model_variants_vs_reference_fixtures(name):
+def test_model_variants_vs_reference_fixtures(name, prec):
     """The HIP path on hyper-parameters off the YAML defaults, against outputs of the reference itself
-    (tests/golden/model_variants.npz): trunk on seeded modulations and full forward on seeded tiles."""
+    (tests/golden/model_variants.npz): trunk on seeded modulations and full forward on seeded tiles.  Both trunk
+    arithmetics ("small" is 3 x 128: the library serves it with the fp32 trunk whatever is asked)."""
     from test_oracle_golden import _variant
 
     g = load_golden("model_variants.npz")
@@ -685,7 +680,7 @@ def test_model_variants_vs_reference_fixtures(name):
     m = ModulatedSiren(dim_in=2, dim_hidden=v["H"], dim_out=1, num_layers=v["L"], latent_dim=v["Z"], w0=v["w0"],
                        w0_initial=v["w0_initial"], use_bias=v["use_bias"], dropout=0.1, modulate=True,
                        encoder_type="custom", encoder_path=None, outer_patch_size=32, inner_patch_size=16,
-                       siren_patch_size=v["S"], device="cuda", activation=v["activation"])
+                       siren_patch_size=v["S"], device="cuda", activation=v["activation"], precision=prec)
     m.load_state_dict(sd)
     m.to("cuda").eval()
     kw = dict(num_layers=v["L"], w0=v["w0"], w0_initial=v["w0_initial"], activation=v["activation"],
