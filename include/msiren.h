@@ -144,6 +144,10 @@ MSIREN_API int msiren_reconstruct_slices_dev(msiren_handle h, const float* image
                                   int32_t width, float* recon_dev);
 MSIREN_API int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t n_slices, int32_t height,
                               int32_t width, float* recon_host);
+/* The same chain from tiles that are already cut (what metrics_error receives, error.py:200-249):
+ * tiles (n*nV*nH, O, O) -> black filter -> model -> zeros re-inserted -> weighted overlap-add -> (n, nV*I, nH*I). */
+MSIREN_API int msiren_reconstruct_tiles_dev(msiren_handle h, const float* tiles_dev, int64_t n_slices, int32_t n_vertical,
+                                 int32_t n_horizontal, float* recon_dev);
 /* Output geometry of the above: nV = ceil(height/I), nH = ceil(width/I); recon is (nV*I, nH*I). */
 MSIREN_API int msiren_recon_shape(msiren_handle h, int32_t height, int32_t width, int32_t* n_vertical, int32_t* n_horizontal);
 
@@ -152,6 +156,12 @@ MSIREN_API int msiren_image_to_patches_dev(msiren_handle h, const float* images_
                                 int32_t width, float* patches_dev /* (n*nV*nH, O, O) */);
 MSIREN_API int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev /* (n*nV*nH, S, S) */, int64_t n_slices,
                              int32_t n_vertical, int32_t n_horizontal, float* recon_dev);
+
+/* patches_to_image (tiling.py:143-181): plain overlap average fold(tiles) / fold(ones) of O x O tiles at stride I,
+ * padding (O-I)/2 -> (n, nV*I, nH*I).  metrics_error folds the fully-sampled and the undersampled tiles with it
+ * to get the images it scores against (error.py:250-255). */
+MSIREN_API int msiren_patches_to_image_dev(msiren_handle h, const float* tiles_dev /* (n*nV*nH, O, O) */, int64_t n_slices,
+                                int32_t n_vertical, int32_t n_horizontal, float* image_dev);
 
 /* Pipelining of asynchronous calls.  n = 1 (default): every *_dev call is enqueued on one stream and
  * executes in call order.  n = 2: consecutive *_dev FORWARD calls (forward_mods/latent/tiles_dev,

@@ -69,9 +69,11 @@ PROTOTYPES = {
     "msiren_forward_tiles_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
     "msiren_reconstruct_slices": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "msiren_reconstruct_slices_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "msiren_reconstruct_tiles_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "msiren_recon_shape": (C.c_int, [_vp, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "msiren_image_to_patches_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "msiren_weighted_fold_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "msiren_patches_to_image_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "msiren_sync": (C.c_int, [_vp]),
     "msiren_set_streams": (C.c_int, [_vp, _i32]),
     "msiren_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),

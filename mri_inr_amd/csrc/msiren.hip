@@ -1266,24 +1266,28 @@ int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev, int64_t n,
     return 0;
 }
 
-// slice pipeline on the CURRENT stream (the host-pointer entry point enqueues its copies around it)
-static int reconstruct_on_current_stream(msiren_handle h, const float* images_dev, int64_t n, int32_t height, int32_t width, float* recon_dev) {
-    int rc;
-    if (n < 0 || (n > 0 && (!images_dev || !recon_dev))) return fail(MSIREN_E_INVALID, "bad arguments");
-    if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles, outer_patch_size=%d", h->O);
+int msiren_patches_to_image_dev(msiren_handle h, const float* tiles_dev, int64_t n, int32_t nV, int32_t nH, float* image_dev) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (n < 0 || nV < 1 || nH < 1 || (n > 0 && (!tiles_dev || !image_dev))) return fail(MSIREN_E_INVALID, "bad arguments");
     if (n == 0) return 0;
-    int32_t nV, nH;
-    if ((rc = msiren_recon_shape(h, height, width, &nV, &nH))) return rc;
+    const int64_t total = n * nV * h->I * (int64_t)nH * h->I;
+    hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->sc[h->cur].s,
+                       tiles_dev, nullptr, image_dev, nullptr, nullptr, n, nV, nH, h->O, h->I, (h->O - h->I) / 2);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// filter -> model -> reintegrate -> weighted fold on tiles that are already on the device (CURRENT stream)
+static int reconstruct_tiles_on_current_stream(msiren_handle h, const float* patches, int64_t n, int32_t nV, int32_t nH, float* recon_dev) {
+    int rc;
     const int64_t NP = n * nV * nH;
-    if ((rc = ensure(h, h->sc[h->cur].patches, (size_t)NP * h->O * h->O * sizeof(float)))) return rc;
     if ((rc = ensure(h, h->sc[h->cur].keep, (size_t)(NP + 64) * sizeof(int)))) return rc;
     if ((rc = ensure(h, h->sc[h->cur].rec, (size_t)NP * h->P * sizeof(float)))) return rc;
     if ((rc = ensure(h, h->sc[h->cur].latent, (size_t)NP * h->Z * sizeof(float)))) return rc;
     if ((rc = ensure(h, h->sc[h->cur].mods, (size_t)h->L * NP * h->H * sizeof(float)))) return rc;
-    float* patches = (float*)h->sc[h->cur].patches.p;
     int* black = (int*)h->sc[h->cur].keep.p;
     float* rec = (float*)h->sc[h->cur].rec.p;
-    if ((rc = msiren_image_to_patches_dev(h, images_dev, n, height, width, patches))) return rc;
     // The reference compacts the non-black tiles, runs the model on those only, and scatters zeros back
     // (tiling.py:244-303).  Same here, on the device: black flags -> list of kept patches (the "plan") ->
     // encoder / modulator / trunk over the kept patches only (their count stays on the device) -> the fold
@@ -1307,6 +1311,31 @@ static int reconstruct_on_current_stream(msiren_handle h, const float* images_de
                        rec, h->d_foldw, recon_dev, black, plan + 2 + NP, n, nV, nH, h->S, h->I, (h->S - h->I) / 2);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// slice pipeline on the CURRENT stream (the host-pointer entry point enqueues its copies around it)
+static int reconstruct_on_current_stream(msiren_handle h, const float* images_dev, int64_t n, int32_t height, int32_t width, float* recon_dev) {
+    int rc;
+    if (n < 0 || (n > 0 && (!images_dev || !recon_dev))) return fail(MSIREN_E_INVALID, "bad arguments");
+    if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles, outer_patch_size=%d", h->O);
+    if (n == 0) return 0;
+    int32_t nV, nH;
+    if ((rc = msiren_recon_shape(h, height, width, &nV, &nH))) return rc;
+    const int64_t NP = n * nV * nH;
+    if ((rc = ensure(h, h->sc[h->cur].patches, (size_t)NP * h->O * h->O * sizeof(float)))) return rc;
+    float* patches = (float*)h->sc[h->cur].patches.p;
+    if ((rc = msiren_image_to_patches_dev(h, images_dev, n, height, width, patches))) return rc;
+    return reconstruct_tiles_on_current_stream(h, patches, n, nV, nH, recon_dev);
+}
+
+int msiren_reconstruct_tiles_dev(msiren_handle h, const float* tiles_dev, int64_t n, int32_t nV, int32_t nH, float* recon_dev) {
+    int rc = check(h);
+    if (rc) return rc;
+    next_stream(h);
+    if (n < 0 || nV < 1 || nH < 1 || (n > 0 && (!tiles_dev || !recon_dev))) return fail(MSIREN_E_INVALID, "bad arguments");
+    if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles, outer_patch_size=%d", h->O);
+    if (n == 0) return 0;
+    return reconstruct_tiles_on_current_stream(h, tiles_dev, n, nV, nH, recon_dev);
 }
 
 int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int64_t n, int32_t height, int32_t width, float* recon_dev) {

@@ -119,7 +119,7 @@ __global__ void weighted_fold_kernel(const float* __restrict__ tiles, const floa
         for (int hh = h0; hh <= h1; ++hh) {
             const int ty = py - v * I, tx = px - hh * I;
             const int64_t b = (s * nV + v) * nH + hh;
-            const float ww = w[ty * S + tx];
+            const float ww = w ? w[ty * S + tx] : 1.f;  // w == nullptr: plain overlap average (patches_to_image, tiling.py:143-181)
             den += ww;
             if (!flags || flags[b] == 0) num += tiles[((pos ? (int64_t)pos[b] : b) * S + ty) * S + tx] * ww;
         }
