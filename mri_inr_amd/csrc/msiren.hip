@@ -24,6 +24,7 @@
 #include "encoder_modulator.hip.h"
 #include "pass_queue.h"
 #include "siren_trunk_f16x3.hip.h"
+#include "siren_trunk_f16x3n.hip.h"
 #include "siren_trunk_f32.hip.h"
 #include "siren_trunk_x1.hip.h"
 #include "tiling.hip.h"
@@ -79,7 +80,10 @@ struct msiren_ctx {
     float *d_grid = nullptr, *d_l0 = nullptr, *d_wp = nullptr, *d_bias = nullptr, *d_wout = nullptr;
     float bout = 0.f, cg0 = 0.f, cg = 0.f;
     // split-fp16 trunk (MSIREN_PREC_F16X3)
-    void* d_wp16 = nullptr;
+    void* d_wp16 = nullptr;   // weight stream of the 32x32x16 kernel (A/B reference, MSIREN_F16_TILE=32)
+    void* d_wp16n = nullptr;  // weight stream of the 16x16x32 kernel (default)
+    int f16_tile = 16;        // MFMA tile of the split-fp16 trunk in use
+    int lds_attr_f16n[2][2] = {};
     float *d_bias16 = nullptr, *d_wout16 = nullptr, *d_s0t = nullptr;
     float winv16[16] = {0};
     bool f16x3_ready = false;
@@ -272,7 +276,7 @@ int pack_trunk_f16x3(msiren_ctx* h) {
     if (h->cfg.precision != MSIREN_PREC_F16X3 || H != 256 || L < 2 || msiren::F16Lds<3>::total(L) > 160 * 1024) return 0;
     const double two_pi = 6.283185307179586476925286766559;
     const double c = (double)h->cfg.w0 / two_pi;
-    std::vector<uint16_t> wp((size_t)(L - 1) * 8 * 16 * 2 * 64 * 8);
+    std::vector<uint16_t> wp((size_t)(L - 1) * 8 * 16 * 2 * 64 * 8), wpn(wp.size());
     std::vector<float> bias((size_t)(L - 1) * 256, 0.f), wout(256, 0.f);
     for (int l = 1; l < L; ++l) {
         const std::vector<float>& w = *get(h, "net.layers." + std::to_string(l) + ".weight");
@@ -296,6 +300,23 @@ int pack_trunk_f16x3(msiren_ctx* h) {
                         wp[base + (size_t)lane * 8 + j] = hi;
                         wp[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
                     }
+        // 16x16x32 kernel (siren_trunk_f16x3n.hip.h): chunk (l, t) = [8 k-steps][2 sub-tiles][hi|lo][64 lanes][8 x f16];
+        // lane (r = lane & 15, q = lane >> 4), element j of k-step s of sub-tile u: output feature 32 t + 16 u + r,
+        // input feature 32 s + 16 (j >> 2) + 4 q + (j & 3)
+        for (int t = 0; t < 8; ++t)
+            for (int s = 0; s < 8; ++s)
+                for (int u = 0; u < 2; ++u)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int f = 32 * t + 16 * u + (lane & 15);
+                            const int k = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+                            const float ws = (float)((double)w[(size_t)f * H + k] * sc);
+                            const uint16_t hi = f32_to_f16_rne(ws);
+                            const uint16_t lo = f32_to_f16_rne(ws - f16_to_f32(hi));
+                            const size_t base = (((((size_t)(l - 1) * 8 + t) * 8 + s) * 2 + u) * 2) * 64 * 8;
+                            wpn[base + (size_t)lane * 8 + j] = hi;
+                            wpn[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
+                        }
         if (const auto* b = h->cfg.use_bias ? get(h, "net.layers." + std::to_string(l) + ".bias") : nullptr)
             for (int f = 0; f < H; ++f) bias[(size_t)(l - 1) * 256 + f] = (float)((double)(*b)[f] * c);
     }
@@ -305,6 +326,12 @@ int pack_trunk_f16x3(msiren_ctx* h) {
     h->d_wp16 = nullptr;
     HIPCHK(hipMalloc(&h->d_wp16, wp.size() * 2));
     HIPCHK(hipMemcpy(h->d_wp16, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+    if (h->d_wp16n) HIPCHK(hipFree(h->d_wp16n));
+    h->d_wp16n = nullptr;
+    HIPCHK(hipMalloc(&h->d_wp16n, wpn.size() * 2));
+    HIPCHK(hipMemcpy(h->d_wp16n, wpn.data(), wpn.size() * 2, hipMemcpyHostToDevice));
+    h->f16_tile = 16;
+    if (const char* e = std::getenv("MSIREN_F16_TILE")) h->f16_tile = std::atoi(e) == 32 ? 32 : 16;  // A/B knob
     int rc;
     if ((rc = upload(&h->d_bias16, bias))) return rc;
     if ((rc = upload(&h->d_wout16, wout))) return rc;
@@ -614,12 +641,32 @@ int launch_trunk_f16x3_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int gri
     return 0;
 }
 
+template <int R>
+int launch_trunk_f16x3n_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int grid) {
+    const int lds = msiren::F16Lds<R>::total(h->L);
+    auto k0 = msiren::siren_trunk_f16x3n_kernel<0, R>;
+    auto k1 = msiren::siren_trunk_f16x3n_kernel<1, R>;
+    const bool mor = h->cfg.activation == MSIREN_ACT_MORLET;
+    const void* kp = mor ? (const void*)k1 : (const void*)k0;
+    int& done = h->lds_attr_f16n[R == 4 ? 1 : 0][mor ? 1 : 0];
+    if (done < lds) {
+        HIPCHK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        done = lds;
+    }
+    if (mor)
+        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
+    else
+        hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     msiren::TrunkF16Params p{};
     p.grid = h->d_grid;
     p.l0 = h->d_l0;
     p.s0t = h->d_s0t;
-    p.wp = (const _Float16*)h->d_wp16;
+    p.wp = (const _Float16*)(h->f16_tile == 16 ? h->d_wp16n : h->d_wp16);
     p.bias = h->d_bias16;
     p.wout = h->d_wout16;
     p.mods = mods_dev;
@@ -646,8 +693,9 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     // call (other stream) to run beside the persistent trunk workgroup; R = 4 fills the CU.
     int ring = (h->nstreams > 1 || h->overlap) ? 3 : 4;
     if (const char* e = std::getenv("MSIREN_F16_RING")) ring = std::atoi(e);
-    if (ring >= 4 && msiren::F16Lds<4>::total(h->L) <= 160 * 1024) return queue_launched(h, launch_trunk_f16x3_r<4>(h, p, grid));
-    return queue_launched(h, launch_trunk_f16x3_r<3>(h, p, grid));
+    const bool r4 = ring >= 4 && msiren::F16Lds<4>::total(h->L) <= 160 * 1024;
+    if (h->f16_tile == 16) return queue_launched(h, r4 ? launch_trunk_f16x3n_r<4>(h, p, grid) : launch_trunk_f16x3n_r<3>(h, p, grid));
+    return queue_launched(h, r4 ? launch_trunk_f16x3_r<4>(h, p, grid) : launch_trunk_f16x3_r<3>(h, p, grid));
 }
 
 int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int grid);
@@ -1070,6 +1118,7 @@ int msiren_destroy(msiren_handle h) {
     if (h->comm) (void)msiren_comm_destroy(h);
     if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
     if (h->d_wp16) (void)hipFree(h->d_wp16);
+    if (h->d_wp16n) (void)hipFree(h->d_wp16n);
     for (void* q : {h->d_wpx1, h->d_biasx1, h->d_woutx1})
         if (q) (void)hipFree(q);
     float* ptrs[] = {h->d_l0last, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};

@@ -7,8 +7,9 @@ Mirrors test_mod_siren.py of the reference (:78-262): build ``ModulatedSiren`` f
 load ``config.testing.model_path``, reconstruct ``config.data.metric_samples`` slices and write
 ``metrics_error.csv`` + ``metrics_summary.txt`` (same formats, :38-75, :236-247) under
 ``{output_dir}/{output_name}/test``.  Differences, all forced by the container:
-  * the slice pipeline (tiling -> black filter -> model -> weighted fold; error.py:231-249) runs on the
-    GPU inside ``model.reconstruct`` instead of torch ops around ``model(tiles)``;
+  * ``image_to_patches`` / ``metrics_error`` are the mirrors in ``mri_inr_amd/harness.py`` (same names, same
+    arguments, :205-232): tiling, black filter, model, weighted fold and the fold of the fully-sampled tiles
+    the reconstruction is scored against (error.py:229-254) run in libmsiren's kernels;
   * ``data.dataset: synthetic`` / ``testing.model_path: synthetic`` select seeded synthetic slices and
     weights (no fastMRI data or checkpoints here); a directory of ``*.npy`` slice pairs
     (``<name>_fully.npy`` / ``<name>_under.npy``) is read otherwise;
@@ -28,7 +29,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from mri_inr_amd import ModulatedSiren, load_configuration, model_kwargs, synthetic  # noqa: E402
 from mri_inr_amd.configuration import parse_args  # noqa: E402
-from mri_inr_amd.metrics import calculate_nrmse, calculate_psnr, calculate_ssim  # noqa: E402
+from mri_inr_amd.harness import image_to_patches, metrics_error  # noqa: E402
 from mri_inr_amd.weights import load_checkpoint  # noqa: E402
 
 
@@ -75,26 +76,27 @@ def test_mod_siren(config):
 
     names, psnrs, ssims, nrmses = [], [], [], []
     t_gpu = 0.0
+    O, I, S = config.model.outer_patch_size, config.model.inner_patch_size, config.model.siren_patch_size
     print("Evaluating metric samples ...")
     for i, (full, under, name) in enumerate(samples(config)):
         print(f"Processing metric sample {i + 1}...")
         t0 = time.perf_counter()
-        rec = model.reconstruct(under)
+        # unsqueeze image to add batch dimension (reference :206-207), tile both images, score
+        fully_sampled_patch, _ = image_to_patches(model, full[None], O, I)
+        undersampled_patch, undersampled_information = image_to_patches(model, under[None], O, I)
+        psnr, ssim, nrmse = metrics_error(model, fully_sampled_patch, undersampled_patch, undersampled_information,
+                                          "cuda", O, I, S)
         t_gpu += time.perf_counter() - t0
-        ref = full[: rec.shape[0], : rec.shape[1]]
-        if ref.shape != rec.shape:  # the reconstruction is padded up to a multiple of inner_patch_size
-            ref = np.pad(ref, ((0, rec.shape[0] - ref.shape[0]), (0, rec.shape[1] - ref.shape[1])), mode="reflect")
         names.append(name)
-        psnrs.append(calculate_psnr(ref, rec))
-        ssims.append(calculate_ssim(ref, rec))
-        nrmses.append(calculate_nrmse(ref, rec))
+        psnrs.append(psnr)
+        ssims.append(ssim)
+        nrmses.append(nrmse)
     with open(os.path.join(output_dir, "metrics_error.csv"), "w") as f:
         f.write("FILENAME,PSNR,SSIM,NRMSE\n")
         for row in zip(names, psnrs, ssims, nrmses):
             f.write(",".join(str(v) for v in row) + "\n")
     save_metrics_summary(psnrs, ssims, nrmses, output_dir)
-    px = sum(1 for _ in names) * 320 * 320
-    print(f"{len(names)} slices reconstructed in {t_gpu:.3f} s host wall (incl. H2D/D2H) -> {output_dir}")
+    print(f"{len(names)} slices scored in {t_gpu:.3f} s host wall (incl. H2D/D2H and the metrics) -> {output_dir}")
     return output_dir
 
 

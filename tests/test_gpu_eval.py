@@ -1,0 +1,120 @@
+"""the evaluation driver end to end on the GPU.  `test_mod_siren.py --config X.yaml` (same CLI
+as the reference's script) must write the reference's artefacts (metrics_error.csv, metrics_summary.txt; formats:
+test_mod_siren.py:38-75,236-247 of the reference) and score the reconstruction against the FOLDED fully-sampled tiles
+(error.py:251-254), also on sizes that are not a multiple of the stride.  PSNR / NRMSE are checked against values
+computed from the fp64 oracle's reconstruction; SSIM is a restatement of scikit-image's definition (not installed
+here): PARITY UNPINNED, only checked for self-consistency."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mri_inr_amd import metrics, synthetic as syn
+from oracle import siren_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+YAML = """
+data:
+  dataset: {data}
+  metric_samples: 0
+  visual_samples: 0
+  acceleration: 6
+  center_fraction: 0.05
+model:
+  dim_in: 2
+  dim_hidden: 256
+  dim_out: 1
+  latent_dim: 256
+  num_layers: 5
+  w0: 1.0
+  w0_initial: 30.0
+  use_bias: true
+  dropout: 0.1
+  encoder_type: custom
+  encoder_path: null
+  outer_patch_size: 32
+  inner_patch_size: 16
+  siren_patch_size: 24
+  activation: sine
+testing:
+  output_dir: {out}
+  output_name: run
+  model_path: synthetic
+"""
+
+
+def test_eval_driver_artefacts_and_scores(tmp_path):
+    data = tmp_path / "data"
+    data.mkdir()
+    sizes = {"a_square": (320, 320), "b_ragged": (200, 136), "c_small": (70, 50)}
+    pairs = {}
+    for k, (name, (hh, ww)) in enumerate(sizes.items()):
+        full = syn.make_slice(10 + k, hh, ww, brain_mask=(name == "a_square"))
+        under = ((full + np.roll(full, 1, 1) + np.roll(full, -1, 1)) / np.float32(3)).astype(np.float32)
+        np.save(data / f"{name}_fully.npy", full)
+        np.save(data / f"{name}_under.npy", under)
+        pairs[name] = (full, under)
+    cfg = tmp_path / "eval.yaml"
+    cfg.write_text(YAML.format(data=data, out=tmp_path / "out"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "test_mod_siren.py"), "--config", str(cfg)], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = tmp_path / "out" / "run" / "test"
+
+    rows = (out / "metrics_error.csv").read_text().splitlines()
+    assert rows[0] == "FILENAME,PSNR,SSIM,NRMSE" and len(rows) == 1 + len(sizes)
+    got = {}
+    for line in rows[1:]:
+        name, psnr, ssim, nrmse = line.split(",")
+        got[name] = (float(psnr), float(ssim), float(nrmse))
+    assert sorted(got) == sorted(sizes)
+
+    summary = (out / "metrics_summary.txt").read_text()
+    m = re.fullmatch(r"(?:(?:PSNR|SSIM|NRMSE):\n(?:  (?:mean|std|min|max): \S+\n){4}\n){3}", summary)
+    assert m, summary
+    assert summary.index("PSNR:") < summary.index("SSIM:") < summary.index("NRMSE:")
+    mean_psnr = float(re.search(r"PSNR:\n  mean: (\S+)", summary).group(1))
+    assert abs(mean_psnr - np.mean([v[0] for v in got.values()])) < 1e-9
+
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    for name, (full, under) in pairs.items():
+        rec = orc.reconstruct_slice(sd, under, num_layers=5, dtype=np.float64)
+        tiles, info = orc.image_to_patches(full, 32, 16)
+        ref = orc.patches_to_image(tiles, info, 32, 16)          # what error.py:251-254 scores against
+        assert ref.shape == rec.shape == (-(-full.shape[0] // 16) * 16, -(-full.shape[1] // 16) * 16)
+        psnr, ssim, nrmse = got[name]
+        assert abs(psnr - metrics.calculate_psnr(ref, rec)) < 2e-3, name            # dB
+        assert abs(nrmse - metrics.calculate_nrmse(ref, rec)) < 1e-4 * nrmse, name
+        assert abs(ssim - metrics.calculate_ssim(ref, rec)) < 1e-4 and -1.0 <= ssim <= 1.0   # self-consistency only
+        if name != "a_square":
+            # the scored image includes the reflect-padded rim beyond the raw slice (ragged sizes)
+            hh, ww = full.shape
+            assert np.allclose(ref[:hh, :ww], full, atol=1e-6)
+            assert ref.shape != full.shape
+
+
+def test_harness_mirror_matches_oracle_tiling():
+    from mri_inr_amd import ModulatedSiren, harness
+
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda", activation="sine")
+    m.load_state_dict(sd)
+    m.to("cuda").eval()
+    imgs = np.stack([syn.make_slice(k, 120, 88, brain_mask=(k == 0)) for k in range(2)])
+    tiles, info = harness.image_to_patches(m, imgs, 32, 16)
+    t0, i0 = orc.image_to_patches(imgs[0], 32, 16)
+    assert info == [tuple(i0)] * 2 and np.array_equal(tiles[: t0.shape[0]], t0)
+    back = harness.patches_to_image(m, tiles, info, 32, 16)
+    assert back.shape == (2, 128, 96)
+    assert np.abs(back[0] - orc.patches_to_image(t0, i0, 32, 16)).max() < 1e-6
+    rec = harness.reconstruct_from_patches(m, tiles, info)
+    assert np.array_equal(rec, m.reconstruct(imgs))              # same chain as the slice entry point, bit for bit
+    with pytest.raises(ValueError):
+        harness.image_to_patches(m, imgs, 32, 8)
