@@ -83,9 +83,10 @@ struct msiren_ctx {
     void* d_wp16 = nullptr;   // weight stream of the 32x32x16 kernel (A/B reference, MSIREN_F16_TILE=32)
     void* d_wp16n = nullptr;  // weight stream of the 16x16x32 kernel (default)
     int f16_tile = 16;        // MFMA tile of the split-fp16 trunk in use
-    int lds_attr_f16n[2][2] = {};
+    int lds_attr_f16n[2][4] = {};
     float *d_bias16 = nullptr, *d_wout16 = nullptr, *d_s0t = nullptr;
-    float winv16[16] = {0};
+    float winv16[16] = {0};    // 32x32 kernel: exact inverse of each hidden layer's power-of-two weight scale
+    float mscale16[16] = {0};  // 16x16 kernel: factor of each layer's modulation row (the NEXT layer's weight scale, inverted)
     bool f16x3_ready = false;
     // single-product 16-bit trunk (MSIREN_PREC_BF16 / MSIREN_PREC_F16), H = 512
     void *d_wpx1 = nullptr, *d_biasx1 = nullptr, *d_woutx1 = nullptr;
@@ -302,24 +303,37 @@ int pack_trunk_f16x3(msiren_ctx* h) {
                     }
         // 16x16x32 kernel (siren_trunk_f16x3n.hip.h): chunk (l, t) = [8 k-steps][2 sub-tiles][hi|lo][64 lanes][8 x f16];
         // lane (r = lane & 15, q = lane >> 4), element j of k-step s of sub-tile u: output feature 32 t + 16 u + r,
-        // input feature 32 s + 16 (j >> 2) + 4 q + (j & 3)
-        for (int t = 0; t < 8; ++t)
-            for (int s = 0; s < 8; ++s)
-                for (int u = 0; u < 2; ++u)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int f = 32 * t + 16 * u + (lane & 15);
-                            const int k = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
-                            const float ws = (float)((double)w[(size_t)f * H + k] * sc);
-                            const uint16_t hi = f32_to_f16_rne(ws);
-                            const uint16_t lo = f32_to_f16_rne(ws - f16_to_f32(hi));
-                            const size_t base = (((((size_t)(l - 1) * 8 + t) * 8 + s) * 2 + u) * 2) * 64 * 8;
-                            wpn[base + (size_t)lane * 8 + j] = hi;
-                            wpn[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
-                        }
+        // input feature 32 s + 16 (j >> 2) + 4 q + (j & 3).  Scale 2^a with rms|W'| ~ 0.1 (a is undone on the
+        // activation side, through the previous layer's modulation row, so the accumulator is the sine argument).
+        {
+            double sq = 0.0;
+            for (float v : w) sq += ((double)v * c) * ((double)v * c);
+            const double rmsw = std::sqrt(sq / (double)w.size());
+            int a = 0;
+            if (rmsw > 0.0) a = (int)std::lround(std::log2(0.1 / rmsw));
+            if (mx > 0.0) a = std::min(a, (int)std::floor(std::log2(32768.0 / mx)));  // stay inside fp16
+            a = std::max(-14, std::min(a, 30));
+            const double scn = std::ldexp(c, a);
+            h->mscale16[l - 1] = (float)std::ldexp(1.0, -a);  // row l-1 of the modulation table
+            for (int t = 0; t < 8; ++t)
+                for (int s2 = 0; s2 < 8; ++s2)
+                    for (int u = 0; u < 2; ++u)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int f = 32 * t + 16 * u + (lane & 15);
+                                const int k = 32 * s2 + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+                                const float ws = (float)((double)w[(size_t)f * H + k] * scn);
+                                const uint16_t hi = f32_to_f16_rne(ws);
+                                const uint16_t lo = f32_to_f16_rne(ws - f16_to_f32(hi));
+                                const size_t base = (((((size_t)(l - 1) * 8 + t) * 8 + s2) * 2 + u) * 2) * 64 * 8;
+                                wpn[base + (size_t)lane * 8 + j] = hi;
+                                wpn[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
+                            }
+        }
         if (const auto* b = h->cfg.use_bias ? get(h, "net.layers." + std::to_string(l) + ".bias") : nullptr)
             for (int f = 0; f < H; ++f) bias[(size_t)(l - 1) * 256 + f] = (float)((double)(*b)[f] * c);
     }
+    h->mscale16[L - 1] = 1.0f;  // the last hidden layer's output meets last_layer unscaled
     const auto* Wo = get(h, "net.last_layer.weight");
     for (int f = 0; f < H; ++f) wout[f] = (float)((double)(*Wo)[f] * c);
     if (h->d_wp16) HIPCHK(hipFree(h->d_wp16));
@@ -331,7 +345,9 @@ int pack_trunk_f16x3(msiren_ctx* h) {
     HIPCHK(hipMalloc(&h->d_wp16n, wpn.size() * 2));
     HIPCHK(hipMemcpy(h->d_wp16n, wpn.data(), wpn.size() * 2, hipMemcpyHostToDevice));
     h->f16_tile = 16;
+#ifdef MSIREN_WITH_TILE32
     if (const char* e = std::getenv("MSIREN_F16_TILE")) h->f16_tile = std::atoi(e) == 32 ? 32 : 16;  // A/B knob
+#endif
     int rc;
     if ((rc = upload(&h->d_bias16, bias))) return rc;
     if ((rc = upload(&h->d_wout16, wout))) return rc;
@@ -619,6 +635,9 @@ int queue_reset_after_plan_launch(msiren_ctx* h) {
     return 0;
 }
 
+// The 32x32x16 kernel (siren_trunk_f16x3.hip.h) is the A/B reference of the 16x16x32 one: compiled in only with
+// -DMSIREN_WITH_TILE32 (make AB32=1), selected at run time with MSIREN_F16_TILE=32.
+#ifdef MSIREN_WITH_TILE32
 template <int R>
 int launch_trunk_f16x3_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int grid) {
     const int lds = msiren::F16Lds<R>::total(h->L);
@@ -641,22 +660,22 @@ int launch_trunk_f16x3_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int gri
     return 0;
 }
 
+#endif
+
 template <int R>
 int launch_trunk_f16x3n_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int grid) {
     const int lds = msiren::F16Lds<R>::total(h->L);
-    auto k0 = msiren::siren_trunk_f16x3n_kernel<0, R>;
-    auto k1 = msiren::siren_trunk_f16x3n_kernel<1, R>;
     const bool mor = h->cfg.activation == MSIREN_ACT_MORLET;
-    const void* kp = mor ? (const void*)k1 : (const void*)k0;
-    int& done = h->lds_attr_f16n[R == 4 ? 1 : 0][mor ? 1 : 0];
+    const bool l5 = h->L == 5;  // the YAML depth has its own straight-line instance (siren_trunk_f16x3n.hip.h: LFIX)
+    using Kern = void (*)(msiren::TrunkF16Params);
+    const Kern k = l5 ? (mor ? (Kern)msiren::siren_trunk_f16x3n_kernel<1, R, 5> : (Kern)msiren::siren_trunk_f16x3n_kernel<0, R, 5>)
+                      : (mor ? (Kern)msiren::siren_trunk_f16x3n_kernel<1, R, 0> : (Kern)msiren::siren_trunk_f16x3n_kernel<0, R, 0>);
+    int& done = h->lds_attr_f16n[R == 4 ? 1 : 0][(mor ? 1 : 0) + (l5 ? 2 : 0)];
     if (done < lds) {
-        HIPCHK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         done = lds;
     }
-    if (mor)
-        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
-    else
-        hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -671,7 +690,7 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     p.wout = h->d_wout16;
     p.mods = mods_dev;
     p.out = out_dev;
-    for (int i = 0; i < 16; ++i) p.winv[i] = h->winv16[i];
+    for (int i = 0; i < 16; ++i) p.winv[i] = h->f16_tile == 16 ? h->mscale16[i] : h->winv16[i];
     p.bout = h->bout;
     p.cg0 = h->cg0;
     p.cg = h->cg;
@@ -694,8 +713,10 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     int ring = (h->nstreams > 1 || h->overlap) ? 3 : 4;
     if (const char* e = std::getenv("MSIREN_F16_RING")) ring = std::atoi(e);
     const bool r4 = ring >= 4 && msiren::F16Lds<4>::total(h->L) <= 160 * 1024;
-    if (h->f16_tile == 16) return queue_launched(h, r4 ? launch_trunk_f16x3n_r<4>(h, p, grid) : launch_trunk_f16x3n_r<3>(h, p, grid));
-    return queue_launched(h, r4 ? launch_trunk_f16x3_r<4>(h, p, grid) : launch_trunk_f16x3_r<3>(h, p, grid));
+#ifdef MSIREN_WITH_TILE32
+    if (h->f16_tile == 32) return queue_launched(h, r4 ? launch_trunk_f16x3_r<4>(h, p, grid) : launch_trunk_f16x3_r<3>(h, p, grid));
+#endif
+    return queue_launched(h, r4 ? launch_trunk_f16x3n_r<4>(h, p, grid) : launch_trunk_f16x3n_r<3>(h, p, grid));
 }
 
 int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int grid);
@@ -1555,9 +1576,9 @@ int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, flo
     if (rc) return rc;
     if (!h->f16x3_ready || h->cfg.activation != MSIREN_ACT_SINE) return fail(MSIREN_E_INVALID, "f16x3 timeline: H=256 sine model required");
     msiren::TrunkF16Params p{};
-    p.grid = h->d_grid; p.l0 = h->d_l0; p.s0t = h->d_s0t; p.wp = (const _Float16*)h->d_wp16; p.bias = h->d_bias16;
+    p.grid = h->d_grid; p.l0 = h->d_l0; p.s0t = h->d_s0t; p.wp = (const _Float16*)(h->f16_tile == 16 ? h->d_wp16n : h->d_wp16); p.bias = h->d_bias16;
     p.wout = h->d_wout16; p.mods = mods_dev; p.out = out_dev;
-    for (int i = 0; i < 16; ++i) p.winv[i] = h->winv16[i];
+    for (int i = 0; i < 16; ++i) p.winv[i] = h->f16_tile == 16 ? h->mscale16[i] : h->winv16[i];
     p.bout = h->bout; p.cg0 = h->cg0; p.cg = h->cg; p.B = (int)B; p.P = h->P; p.L = h->L;
     p.units_per_patch = (h->P + 31) / 32;
     p.total_units = (int)(B * p.units_per_patch);
@@ -1571,9 +1592,19 @@ int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, flo
     p.pass_base = 0;
     p.stamps = (unsigned long long*)st.p;
     const int lds = msiren::F16Lds<4>::total(h->L);
-    auto k = msiren::siren_trunk_f16x3_kernel<0, 4, 1>;
-    HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+#ifdef MSIREN_WITH_TILE32
+    if (h->f16_tile == 32) {
+        auto k = msiren::siren_trunk_f16x3_kernel<0, 4, 1>;
+        HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+    } else
+#endif
+    {
+        if (h->L != 5) return fail(MSIREN_E_INVALID, "f16x3 timeline: the stamped build is the num_layers = 5 instance");
+        auto k = msiren::siren_trunk_f16x3n_kernel<0, 4, 5, 1>;
+        HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(stamps_host, st.p, (size_t)grid * 4 * 48 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

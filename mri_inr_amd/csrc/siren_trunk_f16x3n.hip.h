@@ -21,8 +21,14 @@
 //     12 MFMAs (192 cycles) still reads 4 fragments -- the LDS traffic per FLOP is that of the 32x32 kernel;
 //   * bias / modulation / last_layer tables are per feature, hence shared by the two column groups: they are
 //     read once per 16-feature sub-tile (half the table reads of the 32x32 kernel);
-//   * the fp16 split of the epilogue forms the residual and rounds it in ONE instruction
-//     (v_fma_mixlo_f16 / v_fma_mixhi_f16: lo = f16(v - hi)) instead of v_fma_mix_f32 + a shared v_cvt_pkrtz.
+//   * the accumulator IS the sine argument: the bias (in revolutions) enters as the C operand of a tile's first
+//     MFMAs, and the power-of-two weight scale 2^a of layer l is undone on the other operand -- the modulation
+//     table row of layer l-1 is multiplied by 2^-a when it is copied to LDS -- so W' x' = W x exactly and the
+//     epilogue has no scale/bias FMA.  (a is chosen so that rms|W'| ~ 0.1: the fp16 lo parts of W' and x' then
+//     both sit at the edge of the subnormal range, whose fixed 2^-24 step costs 1-2 of the 22 bits; measured
+//     against the fp64 oracle the kernel stays at the fp32 noise floor, tests/test_gpu_parity.py);
+//   * the epilogue never forms activation x modulation in fp32: hi = f16(a*m) and lo = f16(a*m - hi) are one
+//     v_fma_mix{lo,hi}_f16 each (split_products_pk) -- 2 VALU per element for multiply + split instead of 3.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -30,25 +36,35 @@
 
 namespace msiren {
 
-__device__ __forceinline__ void mfma_n16_first(f32x4& d, const h8& a, const h8& b) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, z, 0, 0, 0);
+// First MFMA of an accumulator: D = A*B + C with C = the bias fragment, a register quad of its own (shared by the
+// two column groups).  Issued through asm: given the builtin with a live C that differs from D, hipcc moves C and the
+// accumulators to the AGPR file and spills.  A (weights) and C, D in arch VGPRs, B (activations) in AGPRs.  D is
+// early-clobber, so it never overlaps C partially (the hardware only supports exact overlap).
+__device__ __forceinline__ void mfma_n16_first(f32x4& d, const h8& a, const h8& b, const f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
 }
 __device__ __forceinline__ void mfma_n16_acc(f32x4& d, const h8& a, const h8& b) {
     d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, d, 0, 0, 0);
 }
 
-// lo halves of a hi/lo pair: {f16(v0 - hi.lo), f16(v1 - hi.hi)}; the residuals are exact in fp32 (hi is the
-// truncation of v to 11 bits), the rounding to fp16 is to nearest
-__device__ __forceinline__ fp16x2 residual_pk(float v0, float v1, fp16x2 hi) {
-    unsigned r;
-    const unsigned hbits = __builtin_bit_cast(unsigned, hi);
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hbits), "v"(v0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(hbits), "v"(v1));
-    return __builtin_bit_cast(fp16x2, r);
+// fp16 hi/lo split of two PRODUCTS a*m (activation x modulation) without forming them in fp32 first:
+//   hi = f16(a*m), lo = f16(a*m - hi), each one v_fma_mix{lo,hi}_f16 -- a single rounding of the exact product,
+// so hi + lo carries 22 bits of a*m.  Four instructions per pair where multiply + v_cvt_pkrtz + residual took five.
+__device__ __forceinline__ void split_products_pk(float a0, float m0, float a1, float m1, fp16x2& hi, fp16x2& lo) {
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(a0), "v"(m0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(a1), "v"(m1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a0), "v"(m0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(a1), "v"(m1), "v"(h));
+    hi = __builtin_bit_cast(fp16x2, h);
+    lo = __builtin_bit_cast(fp16x2, l);
 }
 
-template <int ACT, int R, int DBG = 0>
+// LFIX: 0 = any depth (layer loop at run time); 5 = the YAML depth (num_layers = 5 in every shipped configuration)
+// with the four hidden layers as straight-line code.  The register-resident arrays X, Y then never meet at a loop
+// header, so register allocation does not depend on hipcc coalescing 256 phi copies (which it does for some
+// formulations of the epilogue and not for others: 172 + 228 registers here, 256 + 256 and scratch in the loop form).
+template <int ACT, int R, int LFIX = 0, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Params p) {
     using LY = F16Lds<R>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -57,7 +73,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4;     // which four features of a 16-feature tile this lane holds
     const int n16 = lane & 15;   // coordinate inside a 16-column group
-    const int L = p.L;
+    const int L = p.L;  // == LFIX when LFIX != 0; kept a run-time value: as a constant it lets hipcc unroll the table loops and hoist 60 registers' worth of loads
     const int nchunks = (L - 1) * 8;
 
     // Per-lane byte bases of the LDS tables: every access below is `base + compile-time constant`.
@@ -82,8 +98,9 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
 
     // ---- weight ring (as in the 32x32 kernel) ---------------------------------------------------------
     volatile int* qslot = reinterpret_cast<volatile int*>(smem + LY::queue(L));
-    float* winvT = reinterpret_cast<float*>(smem + LY::winv(L));
-    if (tid < 16) winvT[tid] = p.winv[tid];
+    // p.winv[l] here: factor of the modulation row of layer l (2^-a of layer l+1; 1 for the last hidden layer)
+    float* mscaleT = reinterpret_cast<float*>(smem + LY::winv(L));
+    if (tid < 16) mscaleT[tid] = p.winv[tid];
     int cur_pass = (int)blockIdx.x;
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wp) + wave * 8192 + lane * 16 + 4096;
     int dma_id = 0, dma_buf = 0, rd_buf = 0;
@@ -124,31 +141,39 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
     // acc -> (revolutions) -> activation -> modulation -> fp16 split; parts (g, 0) and (g, 1) make up B fragment
     // [2 t + g] of the next layer.
     fp16x2 eh[4][2], el[4][2];
-    // bias / modulation / last_layer weight of the two sub-tiles of the tile whose epilogue is in flight
-    f32x4 tb_b[2], tb_m[2], tb_w[2];
-    auto tbl_load = [&](int sub, const unsigned char* bl, const unsigned char* ml, const unsigned char* wo, int t, bool withw) {
+    // modulation / last_layer weight of the two sub-tiles of the tile whose epilogue is in flight, and the bias
+    // fragments (C operand) of the two sub-tiles of the NEXT tile
+    f32x4 tb_m[2], tb_w[2], bia[2];
+    auto tbl_load = [&](int sub, const unsigned char* ml, const unsigned char* wo, int t, bool withw) {
         const int fo = (32 * t + 16 * sub) * 4;  // compile-time byte offset
-        tb_b[sub] = *reinterpret_cast<const f32x4*>(bl + fo);
         tb_m[sub] = *reinterpret_cast<const f32x4*>(ml + fo);
         if (withw) tb_w[sub] = *reinterpret_cast<const f32x4*>(wo + fo);
     };
+    auto bias_load = [&](int sub, const unsigned char* bl, int t) {
+        bia[sub] = *reinterpret_cast<const f32x4*>(bl + (32 * t + 16 * sub) * 4);
+        asm("; bias fragment stays in arch VGPRs" : "+v"(bia[sub]));  // left alone hipcc moves it (and the accumulators) to AGPRs and spills
+    };
     // half `hh` (elements 2hh, 2hh+1) of part pt: see epi_half of the 32x32 kernel
-    auto epi_half = [&](const f32x4& a, float winv, float cgl, int pt, int hh, bool lastl) {
+    auto epi_half = [&](const f32x4& a, float cgl, int pt, int hh, bool lastl) {
         const int sub = pt & 1, g = pt >> 1;
-        float a0 = a[2 * hh], a1 = a[2 * hh + 1];
-        asm volatile("; epilogue slice anchored to its MFMA group" : "+v"(a0), "+v"(a1));
-        const float ain[2] = {a0, a1};
         float v[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float r = __builtin_fmaf(ain[e], winv, tb_b[sub][2 * hh + e]);
-            v[e] = activate<ACT>(r, cgl) * tb_m[sub][2 * hh + e];
-            if (lastl) part[g] = __builtin_fmaf(v[e], tb_w[sub][2 * hh + e], part[g]);
+        if constexpr (ACT == 0) {
+            // The sine reads the accumulator (= its argument, in revolutions) directly.  Issued through asm so that it is
+            // anchored to its MFMA group: instruction selection orders pure VALU code only by data dependence and would
+            // emit the whole tile's epilogue in one block ahead of the MFMAs.
+            asm volatile("v_sin_f32 %0, %1" : "=v"(v[0]) : "v"(a[2 * hh]));
+            asm volatile("v_sin_f32 %0, %1" : "=v"(v[1]) : "v"(a[2 * hh + 1]));
+        } else {
+            float a0 = a[2 * hh], a1 = a[2 * hh + 1];
+            asm volatile("; epilogue slice anchored to its MFMA group" : "+v"(a0), "+v"(a1));
+            v[0] = activate<ACT>(a0, cgl);
+            v[1] = activate<ACT>(a1, cgl);
         }
-        if (!lastl) {
-            const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-            eh[pt][hh] = h;
-            el[pt][hh] = residual_pk(v[0], v[1], h);
+        if (lastl) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) part[g] = __builtin_fmaf(v[e] * tb_m[sub][2 * hh + e], tb_w[sub][2 * hh + e], part[g]);
+        } else {
+            split_products_pk(v[0], tb_m[sub][2 * hh], v[1], tb_m[sub][2 * hh + 1], eh[pt][hh], el[pt][hh]);
         }
     };
     auto epi_store2 = [&](int g, h8& dh, h8& dl) {  // column group g of the tile = parts 2g (sub-tile 0), 2g+1 (sub-tile 1)
@@ -161,9 +186,9 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
     // consecutive MFMAs
 #define MSIREN_N16_KSTEP(INh, INl, T, Q, SUB)                                                             \
     do {                                                                                                  \
-        if ((Q) == 0) {                                                                                   \
-            mfma_n16_first(acc[(T) & 1][0 + (SUB)], wf_[(Q) & 1][2 * (SUB) + 1], INh[2 * (Q) + 0]);        \
-            mfma_n16_first(acc[(T) & 1][2 + (SUB)], wf_[(Q) & 1][2 * (SUB) + 1], INh[2 * (Q) + 1]);        \
+        if ((Q) == 0) { /* C = bias (revolutions) of the sub-tile's features, the same for both column groups */ \
+            mfma_n16_first(acc[(T) & 1][0 + (SUB)], wf_[(Q) & 1][2 * (SUB) + 1], INh[2 * (Q) + 0], bia[SUB]); \
+            mfma_n16_first(acc[(T) & 1][2 + (SUB)], wf_[(Q) & 1][2 * (SUB) + 1], INh[2 * (Q) + 1], bia[SUB]); \
         } else {                                                                                          \
             mfma_n16_acc(acc[(T) & 1][0 + (SUB)], wf_[(Q) & 1][2 * (SUB) + 1], INh[2 * (Q) + 0]);          \
             mfma_n16_acc(acc[(T) & 1][2 + (SUB)], wf_[(Q) & 1][2 * (SUB) + 1], INh[2 * (Q) + 1]);          \
@@ -260,19 +285,22 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
             wf_[((Q) + 1) & 1][3] = src_[3 * 64];                                             \
         }                                                                                     \
         if ((T) == 0) {                                                                       \
-            if ((Q) == 0) tbl_load(1, blp_, mlp_, zeroB, 7, false);                           \
+            if ((Q) == 0) tbl_load(1, mlp_, zeroB, 7, false);                                 \
             if ((Q) < 4) {                                                                    \
-                epi_half(acc[1][(Q) & 3], wip_, cgp_, (Q) & 3, 0, false);                     \
-                epi_half(acc[1][(Q) & 3], wip_, cgp_, (Q) & 3, 1, false);                     \
+                epi_half(acc[1][(Q) & 3], cgp_, (Q) & 3, 0, false);                           \
+                epi_half(acc[1][(Q) & 3], cgp_, (Q) & 3, 1, false);                           \
             }                                                                                 \
             if ((Q) == 4) epi_store2(0, INh[14], INl[14]);                                    \
             if ((Q) == 5) epi_store2(1, INh[15], INl[15]);                                    \
         } else {                                                                              \
-            if ((Q) == 0) tbl_load(1, bl_, ml_, wo_, ((T) + 7) & 7, LASTF);                   \
-            epi_half(acc[((T) + 1) & 1][(Q) >> 1], wi_, p.cg, (Q) >> 1, (Q) & 1, LASTF);      \
+            if ((Q) == 0) tbl_load(1, ml_, wo_, ((T) + 7) & 7, LASTF);                        \
+            epi_half(acc[((T) + 1) & 1][(Q) >> 1], p.cg, (Q) >> 1, (Q) & 1, LASTF);           \
             if ((Q) == 5 && !(LASTF)) epi_store2(0, OUTh[(2 * (T) + 14) & 15], OUTl[(2 * (T) + 14) & 15]); \
         }                                                                                     \
-        if ((Q) == 7) tbl_load(0, bl_, ml_, wo_, (T), LASTF); /* sub-tile 0 of THIS tile's epilogue (runs next tile) */ \
+        /* bias fragments of the NEXT tile (its first MFMAs are a group or two away; bia is free after group 0) */ \
+        if ((Q) == 5) bias_load(0, (T) < 7 ? bl_ : bnx_, ((T) + 1) & 7);                      \
+        if ((Q) == 6) bias_load(1, (T) < 7 ? bl_ : bnx_, ((T) + 1) & 7);                      \
+        if ((Q) == 7) tbl_load(0, ml_, wo_, (T), LASTF); /* sub-tile 0 of THIS tile's epilogue (runs next tile) */ \
         MSIREN_N16_KSTEP(INh, INl, T, Q, 0);                                                  \
         MSIREN_N16_KSTEP(INh, INl, T, Q, 1);                                                  \
         MSIREN_N16_SGB();                                                                     \
@@ -307,10 +335,10 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         const int l_ = (LIDX);                                                                \
         const unsigned char* wo_ = woutB; /* read by the final-layer instance only */         \
         const unsigned char* bl_ = biasB + (l_ - 1) * 1024;                                   \
+        /* bias rows of the layer after this one; after the final hidden layer: layer 1 of the next pass */ \
+        const unsigned char* bnx_ = (LASTF) ? biasB : biasB + l_ * 1024;                      \
         const unsigned char* ml_ = modB + l_ * 1024;                                          \
-        const unsigned char* blp_ = l_ > 1 ? biasB + (l_ - 2) * 1024 : zeroB;                 \
         const unsigned char* mlp_ = modB + (l_ - 1) * 1024;                                   \
-        const float wi_ = winvT[l_ - 1], wip_ = l_ > 1 ? winvT[l_ - 2] : 1.0f;              \
         const float cgp_ = l_ > 1 ? p.cg : p.cg0;                                             \
         MSIREN_N16_TILE(INh, INl, OUTh, OUTl, 0, LASTF);                                        \
         MSIREN_N16_TILE(INh, INl, OUTh, OUTl, 1, LASTF);                                        \
@@ -324,6 +352,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * 8) : "memory");
     __syncthreads();  // tables + first chunk visible
+    bias_load(0, biasB, 0);  // layer 1, tile 0 (later passes: loaded at the end of the pass before)
+    bias_load(1, biasB, 0);
     {   // first weight fragments of the very first tile
         const h8* r0 = reinterpret_cast<const h8*>(smem + LY::ring) + lane;
         wf_[0][0] = r0[0 * 64];
@@ -359,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         // this wave's modulation table: (L, 256) floats of patch b
         for (int l = 0; l < L; ++l) {
             const f32x4 m = *reinterpret_cast<const f32x4*>(p.mods + ((size_t)l * p.B + b) * 256 + lane * 4);
-            *reinterpret_cast<f32x4*>(modT + l * 256 + lane * 4) = m;
+            *reinterpret_cast<f32x4*>(modT + l * 256 + lane * 4) = m * mscaleT[l];  // exact: a power of two
         }
         if (tid == 0) qslot[(pass + 1) & 1] = nxt;  // read after >= 32 workgroup barriers
         const float2 xy0 = reinterpret_cast<const float2*>(p.grid)[pc0];
@@ -390,11 +420,9 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
                 fp16x2 hh[2][2], ll[2][2];
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub) {
-                    const f32x4 v = raw[2 * s + g][sub] * m4[sub];
-                    hh[sub][0] = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-                    hh[sub][1] = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-                    ll[sub][0] = residual_pk(v[0], v[1], hh[sub][0]);
-                    ll[sub][1] = residual_pk(v[2], v[3], hh[sub][1]);
+                    const f32x4 a = raw[2 * s + g][sub];
+                    split_products_pk(a[0], m4[sub][0], a[1], m4[sub][1], hh[sub][0], ll[sub][0]);
+                    split_products_pk(a[2], m4[sub][2], a[3], m4[sub][3], hh[sub][1], ll[sub][1]);
                 }
                 Xh[2 * s + g] = to_acc_file(pack_h8(hh[0][0], hh[0][1], hh[1][0], hh[1][1]));
                 Xl[2 * s + g] = to_acc_file(pack_h8(ll[0][0], ll[0][1], ll[1][0], ll[1][1]));
@@ -412,33 +440,40 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
             acc[1][0 + sub] = r0;
             acc[1][2 + sub] = r1;
         }
-        tbl_load(0, zeroB, modB, zeroB, 7, false);  // sub-tile 0 of the layer-0 "pending" tile
+        tbl_load(0, modB, zeroB, 7, false);  // sub-tile 0 of the layer-0 "pending" tile
 
         part[0] = 0.f;
         part[1] = 0.f;
         stamp(1);
         // Hidden layers alternate X->Y and Y->X; the final hidden layer has its own instances (see the 32x32 kernel).
-        for (int l = 1;;) {
-            if (l == L - 1) {
-                MSIREN_N16_LAYER(Xh, Xl, Yh, Yl, l, true);
-                break;
+        if constexpr (LFIX == 5) {
+            MSIREN_N16_LAYER(Xh, Xl, Yh, Yl, 1, false);
+            MSIREN_N16_LAYER(Yh, Yl, Xh, Xl, 2, false);
+            MSIREN_N16_LAYER(Xh, Xl, Yh, Yl, 3, false);
+            MSIREN_N16_LAYER(Yh, Yl, Xh, Xl, 4, true);
+        } else {
+            for (int l = 1;;) {
+                if (l == L - 1) {
+                    MSIREN_N16_LAYER(Xh, Xl, Yh, Yl, l, true);
+                    break;
+                }
+                MSIREN_N16_LAYER(Xh, Xl, Yh, Yl, l, false);
+                ++l;
+                if (l == L - 1) {
+                    MSIREN_N16_LAYER(Yh, Yl, Xh, Xl, l, true);
+                    break;
+                }
+                MSIREN_N16_LAYER(Yh, Yl, Xh, Xl, l, false);
+                ++l;
             }
-            MSIREN_N16_LAYER(Xh, Xl, Yh, Yl, l, false);
-            ++l;
-            if (l == L - 1) {
-                MSIREN_N16_LAYER(Yh, Yl, Xh, Xl, l, true);
-                break;
-            }
-            MSIREN_N16_LAYER(Yh, Yl, Xh, Xl, l, false);
-            ++l;
         }
         stamp(2);
         // the final hidden layer's last tile is still pending: its contribution to `part`
-        tbl_load(1, biasB + (L - 2) * 1024, modB + (L - 1) * 1024, woutB, 7, true);
+        tbl_load(1, modB + (L - 1) * 1024, woutB, 7, true);
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-            epi_half(acc[1][pt], winvT[L - 2], p.cg, pt, 0, true);
-            epi_half(acc[1][pt], winvT[L - 2], p.cg, pt, 1, true);
+            epi_half(acc[1][pt], p.cg, pt, 0, true);
+            epi_half(acc[1][pt], p.cg, pt, 1, true);
         }
         // sum over the four feature sub-groups (q); lanes q == 0 / q == 1 store column group 0 / 1
         float s0v = part[0], s1v = part[1];
