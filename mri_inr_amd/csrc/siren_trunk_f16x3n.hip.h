@@ -270,21 +270,30 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
     // ("pending"), whose result feeds k-step 7 of THIS tile: parts 0..3 in groups 0..3, stores in groups 4 and 5.
     // Tables: sub-tile 0's are read in group 7 of the tile itself, sub-tile 1's in group 0 of the next tile (its
     // registers are still in use by part 3 of the tile before until group 7).
+// Ablation builds (timing only, results wrong; never shipped): -DMSIREN_N16_ABL=bitmask
+//   1 = no epilogue work in the groups, 2 = no ring barrier / vmcnt wait, 4 = no weight-fragment LDS reads, 8 = no DMA
+#ifndef MSIREN_N16_ABL
+#define MSIREN_N16_ABL 0
+#endif
 #define MSIREN_N16_GROUP(INh, INl, OUTh, OUTl, T, Q, LASTF)                                       \
     do {                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        if ((Q) >= 4) { /* two of the eight DMA pieces of chunk c+R-1 per group */            \
+        if ((Q) >= 4 && !(MSIREN_N16_ABL & 8)) { /* two of the eight DMA pieces of chunk c+R-1 per group */ \
             MSIREN_DMA_PIECE(2 * ((Q) & 3));                                                  \
             MSIREN_DMA_PIECE(2 * ((Q) & 3) + 1);                                              \
         }                                                                                     \
-        {                                                                                     \
+        if (MSIREN_N16_ABL & 4) { /* fragments stay what they are, opaquely */               \
+            asm volatile("" : "+v"(wf_[((Q) + 1) & 1][0]), "+v"(wf_[((Q) + 1) & 1][1]), "+v"(wf_[((Q) + 1) & 1][2]), "+v"(wf_[((Q) + 1) & 1][3])); \
+        } else {                                                                              \
             const h8* src_ = (Q) < 7 ? ring_ + (4 * (((Q) + 1) & 7)) * 64 : ringn_;           \
             wf_[((Q) + 1) & 1][0] = src_[0 * 64];                                             \
             wf_[((Q) + 1) & 1][1] = src_[1 * 64];                                             \
             wf_[((Q) + 1) & 1][2] = src_[2 * 64];                                             \
             wf_[((Q) + 1) & 1][3] = src_[3 * 64];                                             \
         }                                                                                     \
-        if ((T) == 0) {                                                                       \
+        if (MSIREN_N16_ABL & 1) { /* keep the accumulators alive so the MFMAs are not dead code */ \
+            if ((Q) == 0) asm volatile("" ::"v"(acc[((T) + 1) & 1][0]), "v"(acc[((T) + 1) & 1][1]), "v"(acc[((T) + 1) & 1][2]), "v"(acc[((T) + 1) & 1][3])); \
+        } else if ((T) == 0) {                                                                       \
             if ((Q) == 0) tbl_load(1, mlp_, zeroB, 7, false);                                 \
             if ((Q) < 4) {                                                                    \
                 epi_half(acc[1][(Q) & 3], cgp_, (Q) & 3, 0, false);                           \
@@ -317,15 +326,17 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         MSIREN_N16_GROUP(INh, INl, OUTh, OUTl, T, 2, LASTF);                                    \
         MSIREN_N16_GROUP(INh, INl, OUTh, OUTl, T, 3, LASTF);                                    \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 8) : "memory");                    \
-        __builtin_amdgcn_s_barrier();                                                         \
+        if (!(MSIREN_N16_ABL & 2)) {                                                          \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * 8) : "memory");                \
+            __builtin_amdgcn_s_barrier();                                                     \
+        }                                                                                     \
         dma_begin();                                                                          \
         MSIREN_N16_GROUP(INh, INl, OUTh, OUTl, T, 4, LASTF);                                    \
         MSIREN_N16_GROUP(INh, INl, OUTh, OUTl, T, 5, LASTF);                                    \
         MSIREN_N16_GROUP(INh, INl, OUTh, OUTl, T, 6, LASTF);                                    \
         MSIREN_N16_GROUP(INh, INl, OUTh, OUTl, T, 7, LASTF);                                    \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        if ((T) > 0 && !(LASTF)) epi_store2(1, OUTh[(2 * (T) + 15) & 15], OUTl[(2 * (T) + 15) & 15]); \
+        if ((T) > 0 && !(LASTF) && !(MSIREN_N16_ABL & 1)) epi_store2(1, OUTh[(2 * (T) + 15) & 15], OUTl[(2 * (T) + 15) & 15]); \
         if constexpr (DBG) { stamp(8 + dbg_tile); ++dbg_tile; }                               \
     } while (0)
 
