@@ -369,7 +369,10 @@ def main():
         # MFMA peak / 3.  The fp32-MFMA peak the north star names is reported next to it.
         dtype, peak = "f16x3", F16_MFMA_PEAK_TFLOPS / 3.0
         dtype_note = "split-fp16: hi/lo fp16 operands, three fp16 MFMAs per product, fp32 accumulate; fp32-equivalent accuracy (1e-4 gate)"
-        kernel = "siren_trunk_f16x3_kernel<%d,4>" % (1 if args.activation == "morlet" else 0)
+        if os.environ.get("MSIREN_F16_TILE") == "32":   # A/B build (make AB32=1) with the 32x32x16 kernel selected
+            kernel = "siren_trunk_f16x3_kernel<%d,4>" % (1 if args.activation == "morlet" else 0)
+        else:                                            # 16x16x32 tiles; the num_layers = 5 straight-line instance
+            kernel = "siren_trunk_f16x3n_kernel<%d,4,%d>" % (1 if args.activation == "morlet" else 0, 5 if L == 5 else 0)
     elif args.precision in ("bf16", "f16"):
         dtype, peak = args.precision, F16_MFMA_PEAK_TFLOPS
         dtype_note = f"{args.precision} MFMA operands, fp32 accumulate"

@@ -105,26 +105,28 @@ def test_model_object_protocol_without_gpu():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """The bench line recorded on the MI355X (profiles/r1/13_final/bench_default.json) carries every key of the
-    driver's contract, the roofline and cpu_baseline objects, and self-consistent arithmetic."""
+    """The bench line recorded on the MI355X (profiles/r2/10_final/bench_default.json) carries every key of the
+    driver's contract, the roofline and cpu_baseline objects, the host->host / slice->slice extras, and
+    self-consistent arithmetic."""
     import json
     import os
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = json.loads(open(os.path.join(root, "profiles", "r1", "13_final", "bench_default.json")).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(root, "profiles", "r2", "10_final", "bench_default.json")).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "extra"):
         assert k in line, k
+    assert line["metric"] == "Mpixels/sec reconstructed (320x320 slice, hidden=256, 5 layers)"
     assert line["unit"] == "Mpixel/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
-    assert line["vs_baseline"] is None and line["data"] == "synthetic" and "workload" in line["config"]
+    assert line["vs_baseline"] is None and line["data"] == "synthetic" and "configs[1]" in line["config"]["workload"]
     assert "model" not in line["config"]
     # value = pixels of all ranks per step / time per step
-    px = line["n_gpus"] * line["config"]["slices_per_gpu_per_step"] * 320 * 320
+    px = line["config"]["slices_per_step_total"] * 320 * 320
     assert abs(line["value"] - px / (line["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * line["value"]
     r = line["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["traffic"] is not None
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
     # algorithmic FLOPs per launch = 525 824 per coordinate x 576 coordinates x 400 tiles (SURVEY.md §8d)
@@ -133,3 +135,10 @@ def test_committed_bench_line_follows_the_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["unit"] == line["unit"] and c["cores"] >= 1
+    e = line["extra"]
+    assert 0 < e["host_to_host_mpixel_s"] < line["value"] and e["reconstruct_mpixel_s"] > 0
+    # the strong-scaling form of BASELINE configs[2] on one GPU, and its 4-rank rehearsal on one card
+    for name, n in (("bench_strong64_n1.json", 1), ("bench_strong64_gloo4_one_card.json", 4)):
+        s = json.loads(open(os.path.join(root, "profiles", "r2", "10_final", name)).read().strip().splitlines()[-1])
+        assert s["scaling"] == "strong" and s["n_gpus"] == n and s["config"]["slices_per_step_total"] == 64
+        assert abs(s["value"] - 64 * 320 * 320 / (s["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * s["value"]
