@@ -126,7 +126,7 @@ def test_committed_bench_line_follows_the_contract():
     r = line["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["traffic"] is not None
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
     # algorithmic FLOPs per launch = 525 824 per coordinate x 576 coordinates x 400 tiles
