@@ -1,5 +1,7 @@
 // Fused modulated-SIREN trunk for gfx950, split-fp16 path ("f16x3"): fp32-equivalent accuracy at
-// 3/16 of the fp32-MFMA cost.
+// 3/16 of the fp32-MFMA cost.  This is round 1's kernel on 32x32x16 MFMA tiles; since round 2 the library
+// ships siren_trunk_f16x3n.hip.h (16x16x32 tiles, same arithmetic and data flow, built on the types and
+// helpers below) and compiles this kernel only as the A/B reference (make AB32=1, MSIREN_F16_TILE=32).
 //
 // Arithmetic.  Every hidden-layer operand is split into two fp16 numbers, v = hi + lo exactly-ish
 // (hi = f16(v), lo = f16(v - hi); 22 significant bits), and the product is evaluated as
@@ -77,18 +79,18 @@ __device__ __forceinline__ h8 pack_h8(fp16x2 a, fp16x2 b, fp16x2 c, fp16x2 d) {
 
 // Register-file placement.  The kernel keeps 256 registers of activations (this layer's and the next
 // layer's B operands) live for a whole layer; they only fit if they sit in the ACCUMULATOR half of the
-// unified 512-register file, which MFMA can read B from directly.  hipcc keeps builtin-MFMA operands
-// in arch VGPRs (and then spills ~300 of them), so the placement is pinned here: values are moved to
-// an "a"-class register once, when produced, and the MFMAs are issued through asm with "a" operands.
+// unified 512-register file, which MFMA can read B from directly.  Left alone hipcc keeps builtin-MFMA
+// operands in arch VGPRs (and then spills ~300 of them), so the placement is pinned here: every B
+// fragment passes through an "a"-constrained asm once, when produced; the MFMAs themselves are the
+// builtin, compiled with -mllvm -amdgpu-mfma-vgpr-form=1 (A and the accumulator in arch VGPRs).
 __device__ __forceinline__ h8 to_acc_file(h8 v) {
     h8 r;
     asm("; activation fragment -> AGPR" : "=a"(r) : "0"(v));
     return r;
 }
 // D = A*B (first k-step of a tile: C = 0) and D += A*B.  A (weights) and the accumulator in arch VGPRs,
-// B (activations) in AGPRs: 2 x 128 activation registers fill the accumulator half exactly.  Hazards hipcc would pad for the builtin are covered by construction:
-// every B fragment is written at least one scheduling group (>100 cycles) before its first use, and
-// an accumulator is read by VALU only in the NEXT tile, behind an s_barrier.
+// B (activations) in AGPRs: 2 x 128 activation registers fill the accumulator half.  Builtins: hipcc
+// inserts whatever hazard padding the operands need.
 __device__ __forceinline__ void mfma_f16_first(f32x16& d, const h8& a, const h8& b) {
     f32x16 z;
 #pragma unroll
