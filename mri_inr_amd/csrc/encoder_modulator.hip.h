@@ -10,6 +10,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef MSIREN_ENC_C3_UNROLL
+#define MSIREN_ENC_C3_UNROLL 32  // weight loads in flight per thread in the fused small-batch kernel's conv3 (8 -> 32: a single tile 67 -> 61.5 us; same summation order, same bits)
+#endif
+
 namespace msiren {
 
 struct EncoderParams {
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256, 5) void encoder_kernel(EncoderParams p, const 
         float s = 0.f;
         const float* w = p.c3w + (size_t)(ks * 512) * 64 + o;
         const float* a = a2 + ks * 512;
-#pragma unroll 8
+#pragma unroll MSIREN_ENC_C3_UNROLL
         for (int k = 0; k < 512; ++k) s = __builtin_fmaf(a[k], w[(size_t)k * 64], s);
         red[ks * 64 + o] = s;
     }

@@ -25,6 +25,7 @@
 #include "pass_queue.h"
 #include "siren_trunk_f16x3.hip.h"
 #include "siren_trunk_f16x3n.hip.h"
+#include "siren_trunk_f16x3h.hip.h"
 #include "siren_trunk_f32.hip.h"
 #include "siren_trunk_x1.hip.h"
 #include "tiling.hip.h"
@@ -84,6 +85,7 @@ struct msiren_ctx {
     void* d_wp16n = nullptr;  // weight stream of the 16x16x32 kernel (default)
     int f16_tile = 16;        // MFMA tile of the split-fp16 trunk in use
     int lds_attr_f16n[2][4] = {};
+    int lds_attr_f16h[2][2] = {};  // half-unit instances (num_layers = 5 only)
     float *d_bias16 = nullptr, *d_wout16 = nullptr, *d_s0t = nullptr;
     float winv16[16] = {0};    // 32x32 kernel: exact inverse of each hidden layer's power-of-two weight scale
     float mscale16[16] = {0};  // 16x16 kernel: factor of each layer's modulation row (the NEXT layer's weight scale, inverted)
@@ -680,6 +682,23 @@ int launch_trunk_f16x3n_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int gr
     return 0;
 }
 
+// half-unit instance (siren_trunk_f16x3h.hip.h): 16 coordinates per wave; depth-5 models only
+template <int R>
+int launch_trunk_f16x3h_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int grid) {
+    const int lds = msiren::F16Lds<R>::total(h->L);
+    const bool mor = h->cfg.activation == MSIREN_ACT_MORLET;
+    using Kern = void (*)(msiren::TrunkF16Params);
+    const Kern k = mor ? (Kern)msiren::siren_trunk_f16x3h_kernel<1, R, 5> : (Kern)msiren::siren_trunk_f16x3h_kernel<0, R, 5>;
+    int& done = h->lds_attr_f16h[R == 4 ? 1 : 0][mor ? 1 : 0];
+    if (done < lds) {
+        HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        done = lds;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     msiren::TrunkF16Params p{};
     p.grid = h->d_grid;
@@ -697,26 +716,45 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     p.B = (int)B;
     p.P = h->P;
     p.L = h->L;
-    p.units_per_patch = (h->P + 31) / 32;
-    const int64_t units = B * p.units_per_patch;
-    if (units > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
-    p.total_units = (int)units;
     p.plan = h->plan;
-    int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
-    if (const char* e = std::getenv("MSIREN_GRID")) grid = std::max(1, std::min(grid, std::atoi(e)));  // experiment knob
-    {   // pass queue: workgroup g starts with pass g, further passes come from this counter
-        int rc = queue_for_launch(h, (units + 3) / 4, &p.pass_counter, &p.pass_base);
-        if (rc) return rc;
-    }
+    const int upp = (h->P + 31) / 32;
+    const int64_t units = B * upp;
+    if (units > 0x3fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     // R = 3 leaves ~35 KB of LDS per CU free, enough for an encoder / modulator workgroup of the NEXT
     // call (other stream) to run beside the persistent trunk workgroup; R = 4 fills the CU.
     int ring = (h->nstreams > 1 || h->overlap) ? 3 : 4;
     if (const char* e = std::getenv("MSIREN_F16_RING")) ring = std::atoi(e);
     const bool r4 = ring >= 4 && msiren::F16Lds<4>::total(h->L) <= 160 * 1024;
+    int cus = h->num_cus;
+    if (const char* e = std::getenv("MSIREN_GRID")) cus = std::max(1, std::min(cus, std::atoi(e)));  // experiment knob
+
+    // One launch of a piece of the batch: units [base, base + count) of `per_wave` coordinates each.  The pass queue
+    // (workgroup g starts with pass g, further passes come from the counter) is claimed per launch.
+    auto launch_piece = [&](bool half, int64_t base, int64_t count) -> int {
+        p.units_per_patch = half ? (h->P + 15) / 16 : upp;
+        p.unit_base = (int)base;
+        p.total_units = (int)count;
+        const int64_t passes = (count + 3) / 4;
+        const int grid = (int)std::min<int64_t>(cus, passes);
+        int rc = queue_for_launch(h, passes, &p.pass_counter, &p.pass_base);
+        if (rc) return rc;
 #ifdef MSIREN_WITH_TILE32
-    if (h->f16_tile == 32) return queue_launched(h, r4 ? launch_trunk_f16x3_r<4>(h, p, grid) : launch_trunk_f16x3_r<3>(h, p, grid));
+        if (h->f16_tile == 32) return queue_launched(h, r4 ? launch_trunk_f16x3_r<4>(h, p, grid) : launch_trunk_f16x3_r<3>(h, p, grid));
 #endif
-    return queue_launched(h, r4 ? launch_trunk_f16x3n_r<4>(h, p, grid) : launch_trunk_f16x3n_r<3>(h, p, grid));
+        if (half) return queue_launched(h, r4 ? launch_trunk_f16x3h_r<4>(h, p, grid) : launch_trunk_f16x3h_r<3>(h, p, grid));
+        return queue_launched(h, r4 ? launch_trunk_f16x3n_r<4>(h, p, grid) : launch_trunk_f16x3n_r<3>(h, p, grid));
+    };
+
+    // Half-unit instance (16 coordinates per wave, twice the waves, about half the time per pass) for small batches:
+    // everything fits in one round even as half-units, so the extra waves are free and the latency drops (a single tile:
+    // 76 -> 66 us).  Needs the unit count on the host (no black-tile plan) and the depth-5 instance.
+    // Measured and dropped: also running the ragged last round of a big launch as a second, half-unit launch (so that all
+    // workgroups of the main launch finish together) -- the second dependent launch costs more than the tail it removes
+    // (one slice: 0.306 vs 0.295 ms; two streams 313 vs 360 Mpixel/s).
+    bool half_ok = h->f16_tile == 16 && !h->plan && h->L == 5;
+    if (const char* e = std::getenv("MSIREN_F16_HALF")) half_ok = half_ok && std::atoi(e) != 0;  // A/B knob
+    if (half_ok && units <= 2 * (int64_t)cus) return launch_piece(true, 0, B * ((h->P + 15) / 16));
+    return launch_piece(false, 0, units);
 }
 
 int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int grid);

@@ -47,6 +47,7 @@ struct TrunkF16Params {
     float winv[16];           // per hidden layer: exact inverse of the power-of-two weight scale
     float bout, cg0, cg;
     int B, P, L, units_per_patch, total_units;
+    int unit_base;            // first unit of this launch (16x16x32 kernels; a launch covers [unit_base, unit_base + total_units))
     const int* plan;          // optional (compact_flags_kernel): the unit count is plan[1] (<= total_units)
     int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
     unsigned pass_base;        // value of *pass_counter when this launch starts (arithmetic is modulo 2^32)

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         (void)dbg_tile;
         int unit = cur_pass * 4 + wave;
         const bool active = unit < total_units;
-        unit = active ? unit : total_units - 1;
+        unit = (active ? unit : total_units - 1) + p.unit_base;
         const int b = unit / p.units_per_patch;
         const int cu = unit - b * p.units_per_patch;
         // the lane's two coordinates (column groups 0 and 1)
