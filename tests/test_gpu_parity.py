@@ -268,6 +268,24 @@ def test_f16x3_trunk_vs_oracle_shapes(L, S, B):
         assert np.array_equal(out[:k], m.forward_mods(mods[:, :k]))
 
 
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_half_unit_trunk_instance_is_bit_identical(act):
+    """Small batches run the half-unit instance of the split-fp16 trunk (16 coordinates per wave,
+    siren_trunk_f16x3h.hip.h); larger ones the 32-coordinate kernel.  Same arithmetic in the same order: a patch
+    must come out bit for bit the same whichever instance evaluated it (and both meet the reference fixture)."""
+    g = load_golden(f"trunk_{act}.npz")
+    sd = syn.make_state_dict(seed=7)
+    m = make_model(sd, act=act, precision="f16x3")
+    mods = syn.make_mods(32, 5, 64, 256)                      # the "uniform_B64" fixture case: 64 x 18 units > 512
+    big = m.forward_mods(mods)
+    check(big.reshape(64, -1), g["uniform_B64"])
+    for n in (1, 5, 28):                                      # <= 28 patches: all units fit one round as half-units
+        small = m.forward_mods(mods[:, :n])
+        assert np.array_equal(small, big[:n]), n
+    one = m.forward_mods(syn.make_mods(31, 5, 1, 256))        # BASELINE configs[0]: a single tile
+    check(one.reshape(1, -1), g["uniform_B1"])
+
+
 def test_f16x3_full_forward_matches_fp32_path():
     sd = syn.make_state_dict(seed=7, trained_like=True)
     m32 = make_model(sd, precision="fp32")
