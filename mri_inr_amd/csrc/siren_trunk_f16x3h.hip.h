@@ -95,9 +95,12 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
         bia[sub] = *reinterpret_cast<const f32x4*>(bl + (32 * t + 16 * sub) * 4);
         asm("; bias fragment stays in arch VGPRs" : "+v"(bia[sub]));
     };
-    auto epi_half = [&](const f32x4& a, float cgl, int sub, int hh, bool lastl) {
+    auto epi_half = [&](const f32x4& a, float cgl, int sub, int hh, bool lastl, bool fresh = false) {
         float v[2];
-        if constexpr (ACT == 0) {
+        if (fresh) {  // accumulator written by the MFMAs just before: builtins, hipcc pads the MFMA -> VALU hazard
+            v[0] = activate<ACT>(a[2 * hh], cgl);
+            v[1] = activate<ACT>(a[2 * hh + 1], cgl);
+        } else if constexpr (ACT == 0) {
             asm volatile("v_sin_f32 %0, %1" : "=v"(v[0]) : "v"(a[2 * hh]));
             asm volatile("v_sin_f32 %0, %1" : "=v"(v[1]) : "v"(a[2 * hh + 1]));
         } else {
@@ -146,8 +149,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
         if ((T) == 0) {                                                                       \
             if ((Q) == 0) tbl_load(1, mlp_, zeroB, 7, false);                                 \
             if ((Q) < 2) {                                                                    \
-                epi_half(acc[1][(Q) & 1], cgp_, (Q) & 1, 0, false);                           \
-                epi_half(acc[1][(Q) & 1], cgp_, (Q) & 1, 1, false);                           \
+                epi_half(acc[1][(Q) & 1], cgp_, (Q) & 1, 0, false, true);                     \
+                epi_half(acc[1][(Q) & 1], cgp_, (Q) & 1, 1, false, true);                     \
             }                                                                                 \
             if ((Q) == 2) epi_store(INh[7], INl[7]);                                          \
         } else {                                                                              \
@@ -289,8 +292,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
         tbl_load(1, modB + (L - 1) * 1024, woutB, 7, true);
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            epi_half(acc[1][sub], p.cg, sub, 0, true);
-            epi_half(acc[1][sub], p.cg, sub, 1, true);
+            epi_half(acc[1][sub], p.cg, sub, 0, true, true);
+            epi_half(acc[1][sub], p.cg, sub, 1, true, true);
         }
         float sv = part;
         sv += __shfl_xor(sv, 16);

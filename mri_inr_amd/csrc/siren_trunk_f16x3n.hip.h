@@ -36,12 +36,12 @@
 
 namespace msiren {
 
-// First MFMA of an accumulator: D = A*B + C with C = the bias fragment, a register quad of its own (shared by the
-// two column groups).  Issued through asm: given the builtin with a live C that differs from D, hipcc moves C and the
-// accumulators to the AGPR file and spills.  A (weights) and C, D in arch VGPRs, B (activations) in AGPRs.  D is
-// early-clobber, so it never overlaps C partially (the hardware only supports exact overlap).
+// First MFMA of an accumulator: D = A*B + C with C = the bias fragment, a register quad of its own (shared by the two
+// column groups).  The builtin, so that hipcc sees every MFMA -> MFMA dependency and pads the hazards itself (an asm
+// MFMA here once produced wrong results under another sched_group_barrier pattern: hipcc cannot know that an asm
+// statement is an MFMA whose result the next MFMA must not read as SrcC a few cycles later).
 __device__ __forceinline__ void mfma_n16_first(f32x4& d, const h8& a, const h8& b, const f32x4& c) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ void mfma_n16_acc(f32x4& d, const h8& a, const h8& b) {
     d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, d, 0, 0, 0);
@@ -154,10 +154,15 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         asm("; bias fragment stays in arch VGPRs" : "+v"(bia[sub]));  // left alone hipcc moves it (and the accumulators) to AGPRs and spills
     };
     // half `hh` (elements 2hh, 2hh+1) of part pt: see epi_half of the 32x32 kernel
-    auto epi_half = [&](const f32x4& a, float cgl, int pt, int hh, bool lastl) {
+    // `fresh`: the accumulator was written by the MFMAs just before (the "pending" tile of the previous layer): plain
+    // builtins, so that hipcc pads the MFMA -> VALU read hazard.  Elsewhere the accumulator is one tile (>= 12 MFMAs) old.
+    auto epi_half = [&](const f32x4& a, float cgl, int pt, int hh, bool lastl, bool fresh = false) {
         const int sub = pt & 1, g = pt >> 1;
         float v[2];
-        if constexpr (ACT == 0) {
+        if (fresh) {
+            v[0] = activate<ACT>(a[2 * hh], cgl);
+            v[1] = activate<ACT>(a[2 * hh + 1], cgl);
+        } else if constexpr (ACT == 0) {
             // The sine reads the accumulator (= its argument, in revolutions) directly.  Issued through asm so that it is
             // anchored to its MFMA group: instruction selection orders pure VALU code only by data dependence and would
             // emit the whole tile's epilogue in one block ahead of the MFMAs.
@@ -242,6 +247,63 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
         __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                    \
     } while (0)
+#elif MSIREN_N16_SGB_VARIANT == 3  /* all LDS reads of the group up front, then one VALU per MFMA */
+#define MSIREN_N16_SGB()                                                                      \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                    \
+    } while (0)
+#elif MSIREN_N16_SGB_VARIANT == 4  /* two LDS reads behind each of the first MFMAs, VALU from the fifth MFMA on */
+#define MSIREN_N16_SGB()                                                                      \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                    \
+    } while (0)
 #else  /* 2: MFMAs in pairs (same A operand back to back), two VALU after each pair */
 #define MSIREN_N16_SGB()                                                                      \
     do {                                                                                      \
@@ -296,8 +358,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         } else if ((T) == 0) {                                                                       \
             if ((Q) == 0) tbl_load(1, mlp_, zeroB, 7, false);                                 \
             if ((Q) < 4) {                                                                    \
-                epi_half(acc[1][(Q) & 3], cgp_, (Q) & 3, 0, false);                           \
-                epi_half(acc[1][(Q) & 3], cgp_, (Q) & 3, 1, false);                           \
+                epi_half(acc[1][(Q) & 3], cgp_, (Q) & 3, 0, false, true);                     \
+                epi_half(acc[1][(Q) & 3], cgp_, (Q) & 3, 1, false, true);                     \
             }                                                                                 \
             if ((Q) == 4) epi_store2(0, INh[14], INl[14]);                                    \
             if ((Q) == 5) epi_store2(1, INh[15], INl[15]);                                    \
@@ -483,8 +545,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         tbl_load(1, modB + (L - 1) * 1024, woutB, 7, true);
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-            epi_half(acc[1][pt], p.cg, pt, 0, true);
-            epi_half(acc[1][pt], p.cg, pt, 1, true);
+            epi_half(acc[1][pt], p.cg, pt, 0, true, true);
+            epi_half(acc[1][pt], p.cg, pt, 1, true, true);
         }
         // sum over the four feature sub-groups (q); lanes q == 0 / q == 1 store column group 0 / 1
         float s0v = part[0], s1v = part[1];

@@ -18,7 +18,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int SHAPE, int MODE>
+template <int SHAPE, int MODE, int BAGPR = 0>
 __global__ void __launch_bounds__(256, 1) k(float* out, const _Float16* src, int iters, int wgs_active) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     if ((int)blockIdx.x >= wgs_active) return;
@@ -27,6 +27,12 @@ __global__ void __launch_bounds__(256, 1) k(float* out, const _Float16* src, int
     for (int q = 0; q < 16; ++q) {
         xh[q] = *reinterpret_cast<const h8*>(src + ((threadIdx.x * 16 + q) * 8) % 32768);
         xl[q] = *reinterpret_cast<const h8*>(src + ((threadIdx.x * 16 + q) * 8 + 16384) % 32768);
+    }
+    if (BAGPR) {  // B operands in the accumulator half of the register file, as in the trunk
+        for (int q = 0; q < 16; ++q) {
+            asm("; B -> AGPR" : "=a"(xh[q]) : "0"(xh[q]));
+            asm("; B -> AGPR" : "=a"(xl[q]) : "0"(xl[q]));
+        }
     }
     for (int i = threadIdx.x; i < 32768; i += 256) reinterpret_cast<_Float16*>(lds)[i] = src[i];  // 64 KB of "weights"
     __syncthreads();
@@ -79,11 +85,11 @@ __global__ void __launch_bounds__(256, 1) k(float* out, const _Float16* src, int
     if (r == 12345.678f) out[threadIdx.x] = r;
 }
 
-template <int SHAPE, int MODE>
+template <int SHAPE, int MODE, int BAGPR = 0>
 void run(const char* name, float* d_out, _Float16* d_src, int wgs, int iters) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    auto kern = k<SHAPE, MODE>;
+    auto kern = k<SHAPE, MODE, BAGPR>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipLaunchKernelGGL(kern, dim3(256), dim3(256), 65536, 0, d_out, d_src, iters / 4, wgs);  // warm / clock settle
     (void)hipEventRecord(e0, 0);
@@ -115,6 +121,8 @@ int main() {
             run<1, 1>("16x16x32 + LDS fragment reads (pipelined)", d_out, d_src, wgs, iters);
             run<0, 2>("32x32x16 + LDS reads + epilogue VALU", d_out, d_src, wgs, iters);
             run<1, 2>("16x16x32 + LDS reads + epilogue VALU", d_out, d_src, wgs, iters);
+            run<1, 0, 1>("16x16x32, registers only, B in AGPRs", d_out, d_src, wgs, iters);
+            run<1, 1, 1>("16x16x32 + LDS reads, B in AGPRs", d_out, d_src, wgs, iters);
         }
     return 0;
 }
