@@ -404,6 +404,9 @@ def main():
         "roofline": {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "traffic": traffic_bytes(kernel), "kernel": kernel,
+            # achieved HBM/fabric rate of the kernel, to show how far from the 8 TB/s roof it is
+            "hbm_gb_s": (traffic_bytes(kernel) / trunk_avg_s / 1e9) if (traffic_bytes(kernel) and trunk_avg_s > 0 and n_sl == 1) else None,
+            "hbm_peak_gb_s": 8000.0,
             "flops_per_launch": flops_launch, "avg_launch_ms": trunk_avg_s * 1e3, "launches": int(launches.value),
             "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
             # tools/mfma_peak_probe.hip: all 256 CUs issuing only fp16 MFMAs sustain 1476 TFLOP/s under the

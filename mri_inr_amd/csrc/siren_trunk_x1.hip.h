@@ -188,10 +188,12 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
     // half `hh` (elements 2hh, 2hh+1) of part g; `old` = the fragment that holds the same features of the
     // layer's INPUT (word 2(g&1)+hh), `rflag` = 1 where the residual applies (0 for the layer-0 tile)
     // lastl = final hidden layer (own code instances): accumulate last_layer's dot product, produce no fragment
+    // `fresh`: the accumulator was written by the MFMAs just before ("pending" tile of the previous layer): no asm anchor
+    // in between, so that hipcc sees the MFMA -> VALU read and pads the hazard (an asm statement hides the producer).
     auto epi_half = [&](const f32x16& a, float winv, float cgl, int set, int g, int hh, const u32x4& old, float rflag,
-                        bool lastl) {
+                        bool lastl, bool fresh = false) {
         float a0 = a[4 * g + 2 * hh], a1 = a[4 * g + 2 * hh + 1];
-        asm volatile("; epilogue slice anchored to its MFMA group" : "+v"(a0), "+v"(a1));
+        if (!fresh) asm volatile("; epilogue slice anchored to its MFMA group" : "+v"(a0), "+v"(a1));
         const float ain[2] = {a0, a1};
         float xo[2] = {0.f, 0.f};
         if constexpr (RES) x1_unpack2<BF>(old[2 * (g & 1) + hh], xo[0], xo[1]);
@@ -229,8 +231,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
             /* pending tile 15 of the previous layer: its input fragments are OUT[30], OUT[31] */ \
             if ((Q) < 3) tbl_load(((Q) + 1) & 1, blp_, mlp_, zeroB, 15, ((Q) + 1) & 3, false); \
             if ((Q) < 4) {                                                                    \
-                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 0, OUT[30 + (((Q) & 3) >> 1)], rfp_, false); \
-                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 1, OUT[30 + (((Q) & 3) >> 1)], rfp_, false); \
+                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 0, OUT[30 + (((Q) & 3) >> 1)], rfp_, false, true); \
+                epi_half(acc[1], wip_, cgp_, (Q) & 1, (Q) & 3, 1, OUT[30 + (((Q) & 3) >> 1)], rfp_, false, true); \
             }                                                                                 \
             if ((Q) == 4) epi_store1(0, IN[30]);                                              \
             if ((Q) == 5) epi_store1(1, IN[31]);                                              \
@@ -291,8 +293,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1_kernel(TrunkX1Params p)
 #define MSIREN_X1_FINAL_G(IN, G)                                                                     \
     {                                                                                                \
         if ((G) > 0) tbl_load((G) & 1, biasB + (L - 2) * 1024, modB + (L - 1) * 1024, woutB, 15, (G), true); \
-        epi_half(acc[1], winvT[L - 2], p.cg, (G) & 1, (G), 0, IN[30 + ((G) >> 1)], 1.0f, true);      \
-        epi_half(acc[1], winvT[L - 2], p.cg, (G) & 1, (G), 1, IN[30 + ((G) >> 1)], 1.0f, true);      \
+        epi_half(acc[1], winvT[L - 2], p.cg, (G) & 1, (G), 0, IN[30 + ((G) >> 1)], 1.0f, true, true); \
+        epi_half(acc[1], winvT[L - 2], p.cg, (G) & 1, (G), 1, IN[30 + ((G) >> 1)], 1.0f, true, true); \
     }
 
 #define MSIREN_X1_LAYER(IN, OUT, LIDX, LASTF)                                                  \
