@@ -257,10 +257,24 @@ def main():
         model.to(f"cuda:{dev}").eval()
         group = tgroup
     else:
-        group = RcclGroup(model)          # communicator through the C ABI (no-op for one rank)
-        if rank == 0:
-            model._sd.update({k: np.ascontiguousarray(v, dtype=np.float32) for k, v in sd.items()})
-        group.broadcast_weights(0)        # load_state_dict on rank 0 only; one ncclBroadcast of the blob
+        try:
+            group = RcclGroup(model)      # communicator through the C ABI (no-op for one rank)
+            if rank == 0:
+                model._sd.update({k: np.ascontiguousarray(v, dtype=np.float32) for k, v in sd.items()})
+            group.broadcast_weights(0)    # load_state_dict on rank 0 only; one ncclBroadcast of the blob
+        except Exception as exc:  # noqa: BLE001 -- keep the measurement alive if RCCL cannot come up on this node
+            if world == 1:
+                raise
+            # Fallback, said out loud in the JSON line: the weights are synthetic and seeded, so every rank can build
+            # its own copy (the broadcast is outside the timed region anyway); barrier and MAX go over gloo on the CPU.
+            # No torch.cuda call is made: the process keeps its one HIP runtime.
+            print(f"[rank {rank}] RCCL through the C ABI failed ({exc}); falling back to seeded weights + gloo",
+                  file=sys.stderr, flush=True)
+            backend = "gloo-fallback"
+            group = TorchGroup("gloo", rank, world, dev)
+            sd = syn.make_state_dict(seed=7, dim_hidden=H, num_layers=L, latent_dim=Z, **kw)
+            model.load_state_dict(sd)
+            model.to(f"cuda:{dev}")
         model.eval()
     lib, h = model._lib, model._h
 
@@ -398,7 +412,9 @@ def main():
             "precision": args.precision, "streams": args.streams, "pipeline": args.pipeline, "brain_mask": bool(args.brain_mask),
             "parallelism": f"slice-shard x{world} ({scaling}; no data-path collective, one weight broadcast at load)",
             "backend": {"rccl": "RCCL through libmsiren's C ABI (torch-free)", "nccl": "torch.distributed nccl (RCCL)",
-                        "gloo": "torch.distributed gloo (rehearsal: ranks may share a card)"}[backend] if world > 1 else "single process",
+                        "gloo": "torch.distributed gloo (rehearsal: ranks may share a card)",
+                        "gloo-fallback": "RCCL init failed on this node: seeded weights on every rank, barrier/MAX over gloo"}[backend]
+                       if world > 1 else "single process",
             "warmup_steps_run": warm_steps,
         },
         "roofline": {

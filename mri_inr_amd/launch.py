@@ -73,6 +73,8 @@ def spawn_ranks(argv: list[str], world: int, *, timeout: float | None = None, en
         p = subprocess.Popen(argv, env=rank_env(r, world, port, base=env), stdout=subprocess.PIPE,
                              stderr=subprocess.PIPE, text=True, bufsize=1)
         procs.append(p)
+        stderr.write(f"[launch] rank {r} of {world} started (pid {p.pid})\n")
+        stderr.flush()
         pumps.append(threading.Thread(target=_pump, daemon=True,
                                       args=(p.stdout, stdout if r == 0 else stderr, "" if r == 0 else f"[rank {r}] ",
                                             rank0_out if r == 0 else None)))
