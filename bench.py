@@ -237,7 +237,7 @@ def main():
     ndev = _lib.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a gfx950 GPU (the HIP path has no CPU fallback)")
-    if backend != "gloo" and world > ndev:
+    if backend != "gloo" and world > ndev and not os.environ.get("MSIREN_BENCH_ALLOW_SHARED"):  # (test knob: lets RCCL refuse the shared card)
         raise SystemExit(f"{world} ranks but {ndev} GPU(s) visible: one rank per GPU (MSIREN_BENCH_BACKEND=gloo rehearses "
                          f"several ranks on one card)")
     dev = local_rank % ndev

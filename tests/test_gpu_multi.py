@@ -163,6 +163,18 @@ def test_bench_gpus2_starts_its_own_ranks_gloo_rehearsal_on_one_card():
     assert abs(s["value"] - 6 * 320 * 320 / s["ms_per_step"] / 1e3) < 1e-6 * s["value"]
 
 
+def test_bench_two_rccl_ranks_on_one_card_rendezvous_then_fall_back():
+    """Two self-launched ranks with the default (RCCL, torch-free) backend on the ONE card of this box: the unique-id
+    rendezvous and ncclCommInitRank run across the two processes for real, RCCL then refuses the shared device
+    ("invalid usage"), and bench.py falls back to seeded weights + gloo plumbing instead of losing the measurement --
+    the JSON line says so."""
+    d = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"], {"MSIREN_BENCH_ALLOW_SHARED": "1"},
+               timeout=400)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert "RCCL init failed" in d["config"]["backend"]
+    assert abs(d["value"] - 2 * 320 * 320 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+
+
 def test_bench_strong_scaling_config3_single_gpu():
     d = _bench(["--total-slices", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
     assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["patches_per_step_rank0"] == 25600
