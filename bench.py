@@ -259,9 +259,7 @@ def main():
     else:
         try:
             group = RcclGroup(model)      # communicator through the C ABI (no-op for one rank)
-            if rank == 0:
-                model._sd.update({k: np.ascontiguousarray(v, dtype=np.float32) for k, v in sd.items()})
-            group.broadcast_weights(0)    # load_state_dict on rank 0 only; one ncclBroadcast of the blob
+            group.broadcast_weights(0, sd)  # load_state_dict on rank 0 only (sd is None elsewhere); one ncclBroadcast
         except Exception as exc:  # noqa: BLE001 -- keep the measurement alive if RCCL cannot come up on this node
             if world == 1:
                 raise

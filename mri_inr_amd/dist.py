@@ -120,11 +120,14 @@ class RcclGroup:
             blob = exchange_from_rank0(bytes(uid.raw) if self.rank == 0 else None, env=env)
             _lib.check(self._lib.msiren_comm_init_rank(self._h, blob, len(blob), self.world, self.rank))
 
-    def broadcast_weights(self, src: int = 0):
-        """load_state_dict on ``src`` only; every rank ends up with its weights, committed."""
+    def broadcast_weights(self, src: int = 0, state_dict=None):
+        """load_state_dict on ``src`` only (pass the state_dict there, None elsewhere); every rank ends up with the
+        source's weights, committed, and with its ``state_dict()`` mirror in step."""
         from . import _lib
 
         if self.rank == src:
+            if state_dict is not None:
+                self.model.load_state_dict(state_dict)
             self.model._push_tensors()
         if self.world == 1:
             self.model._ensure_committed()

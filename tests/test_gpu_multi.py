@@ -83,7 +83,7 @@ def test_rccl_group_object_and_comm_init_all():
                                   outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda:0", activation="sine")
         tiles = np.random.default_rng(0).random((5, 32, 32), dtype=np.float32)
         ref = model(); ref.load_state_dict(sd); want = ref(tiles)
-        m = model(); g = RcclGroup(m); m._sd.update(sd); g.broadcast_weights(0); g.barrier()
+        m = model(); g = RcclGroup(m); g.broadcast_weights(0, sd); g.barrier()
         assert g.max(3.5) == 3.5 and np.array_equal(m(tiles), want)
         g.destroy()
         m2 = model(); m2._sd.update(sd); m2._push_tensors()
