@@ -286,6 +286,35 @@ def test_half_unit_trunk_instance_is_bit_identical(act):
     check(one.reshape(1, -1), g["uniform_B1"])
 
 
+@pytest.mark.parametrize("wscale,mlo,mhi", [(1.0, 0.5, 1.5), (0.25, 0.5, 1.5), (4.0, 0.05, 0.15), (1.0, 0.0005, 0.002),
+                                            (0.5, 5.0, 20.0), (2.0, 0.5, 1.5)])
+def test_f16x3_scale_folding_over_weight_and_modulation_magnitudes(wscale, mlo, mhi):
+    """The split-fp16 trunk scales each hidden layer's weights by 2^a (rms|W'| ~ 0.1) and undoes it on the activation side
+    through the previous layer's modulation row, so both fp16 `lo` parts sit at the edge of the subnormal range.  Small /
+    large weights and tiny / large modulations move operands deeper into it (or towards overflow): the kernel must stay
+    at the fp32 noise floor of the same model (reference arithmetic: modulated_siren.py:215-233 in fp32 vs fp64)."""
+    L, B = 5, 40
+    sd = syn.make_state_dict(seed=11, with_encoder=False)
+    sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
+    for l in range(1, L):
+        sd[f"net.layers.{l}.weight"] = (sd[f"net.layers.{l}.weight"] * np.float32(wscale)).astype(np.float32)
+    m = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=L, latent_dim=256, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda", activation="sine",
+                       precision="f16x3")
+    m.load_state_dict(sd, strict=False)
+    m.to("cuda")
+    mods = syn.make_mods(5, L, B, 256, lo=mlo, hi=mhi)
+    out = m.forward_mods(mods).reshape(B, -1)
+    ref64 = orc.siren_forward(sd, mods, num_layers=L, dtype=np.float64)
+    ref32 = orc.siren_forward(sd, mods, num_layers=L)
+    assert np.isfinite(out).all()
+    scale = max(np.abs(ref64).max(), 1e-30)
+    e64, e32 = np.abs(out - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale
+    assert e64 <= max(10 * e32, 2e-5), (e64, e32)
+    assert e64 <= 1e-4 or e32 > 2e-5, (e64, e32)   # the gate, unless fp32 itself is already that far from fp64 here
+
+
 def test_f16x3_full_forward_matches_fp32_path():
     sd = syn.make_state_dict(seed=7, trained_like=True)
     m32 = make_model(sd, precision="fp32")
