@@ -745,12 +745,15 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
         return queue_launched(h, r4 ? launch_trunk_f16x3n_r<4>(h, p, grid) : launch_trunk_f16x3n_r<3>(h, p, grid));
     };
 
-    // Half-unit instance (16 coordinates per wave, twice the waves, about half the time per pass) for small batches:
-    // everything fits in one round even as half-units, so the extra waves are free and the latency drops (a single tile:
-    // 76 -> 66 us).  Needs the unit count on the host (no black-tile plan) and the depth-5 instance.
-    // Measured and dropped: also running the ragged last round of a big launch as a second, half-unit launch (so that all
-    // workgroups of the main launch finish together) -- the second dependent launch costs more than the tail it removes
-    // (one slice: 0.306 vs 0.295 ms; two streams 313 vs 360 Mpixel/s).
+    // Half-unit instance (16 coordinates per wave, twice the waves) for small batches: everything fits in one round even
+    // as half-units, so the extra waves are free and the latency drops (a single tile: 76 -> 66 us).  Needs the unit count
+    // on the host (no black-tile plan) and the depth-5 instance.
+    // Measured and dropped, twice: running the ragged last round of a big launch (one 320x320 slice = 7.03 rounds of
+    // 256 x 4 waves) as half-units so that the main launch's workgroups finish together -- (1) as a second launch behind
+    // the main one on the same stream: 0.306 vs 0.295 ms per slice; (2) queued beside it on the handle's idle second
+    // stream (event fork / join, no launch gap): 0.315 vs 0.289 ms.  A half-unit pass on an otherwise idle chip is not
+    // half a round (its weight-fragment reads are those of a full unit; prologue and layer 0 do not shrink), and the
+    // cross-stream dependency costs more than the tail it removes.
     bool half_ok = h->f16_tile == 16 && !h->plan && h->L == 5;
     if (const char* e = std::getenv("MSIREN_F16_HALF")) half_ok = half_ok && std::atoi(e) != 0;  // A/B knob
     if (half_ok && units <= 2 * (int64_t)cus) return launch_piece(true, 0, B * ((h->P + 15) / 16));
