@@ -104,10 +104,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
             asm volatile("v_sin_f32 %0, %1" : "=v"(v[0]) : "v"(a[2 * hh]));
             asm volatile("v_sin_f32 %0, %1" : "=v"(v[1]) : "v"(a[2 * hh + 1]));
         } else {
-            float a0 = a[2 * hh], a1 = a[2 * hh + 1];
-            asm volatile("; epilogue slice anchored to its MFMA group" : "+v"(a0), "+v"(a1));
-            v[0] = activate<ACT>(a0, cgl);
-            v[1] = activate<ACT>(a1, cgl);
+            // Morlet: sin(2 pi r) * exp2(cg r^2).  The sine and the first factor of the exponent are issued through one asm
+            // (the anchor of this slice; no copy of the accumulator), the rest depends on its outputs.
+            float s0, s1, t0, t1;
+            asm volatile("v_sin_f32 %0, %2\n\tv_mul_f32 %1, %3, %2" : "=&v"(s0), "=&v"(t0) : "v"(a[2 * hh]), "v"(cgl));
+            asm volatile("v_sin_f32 %0, %2\n\tv_mul_f32 %1, %3, %2" : "=&v"(s1), "=&v"(t1) : "v"(a[2 * hh + 1]), "v"(cgl));
+            v[0] = s0 * __builtin_amdgcn_exp2f(t0 * a[2 * hh]);
+            v[1] = s1 * __builtin_amdgcn_exp2f(t1 * a[2 * hh + 1]);
         }
         if (lastl) {
 #pragma unroll
