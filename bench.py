@@ -106,7 +106,7 @@ def traffic_bytes(kernel):
     """HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes (collected with
     tools/profile.sh: separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction); None if the
     profile on record is for another kernel."""
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         try:
             d = json.load(open(os.path.join(REPO, "profiles", rnd, "traffic.json")))
         except Exception:
@@ -117,7 +117,8 @@ def traffic_bytes(kernel):
 
 
 def cpu_baseline(sd, tiles, activation, budget_s):
-    """The torch-CPU twin (oracle/torch_twin.py, "port") timed on this box's host cores."""
+    """The torch-CPU twin (oracle/torch_twin.py, "port") timed on this box's host cores: best of 5 full slices after
+    2 warm-up slices; the wall budget only cuts the repetitions short on a very slow host."""
     import torch
 
     from oracle import torch_twin as tw
@@ -126,19 +127,26 @@ def cpu_baseline(sd, tiles, activation, budget_s):
     torch.set_num_threads(cores)
     t = tw.to_tensors(sd)
     x = torch.from_numpy(tiles)
-    tw.forward_tiles(t, x[:64], num_layers=5, activation=activation)  # warm-up (baseline model only)
-    n, t0 = 0, time.perf_counter()
-    while True:
+    t_begin = time.perf_counter()
+    warm = 0
+    for _ in range(2):
         tw.forward_tiles(t, x, num_layers=5, activation=activation)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 64:
+        warm += 1
+        if time.perf_counter() - t_begin > budget_s / 2:
             break
-    px = n * 320 * 320
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        tw.forward_tiles(t, x, num_layers=5, activation=activation)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_begin > budget_s:
+            break
+    best = min(times)
     return {
-        "value": px / el / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port",
-        "sample": f"{n} x (one 320x320 slice = 400 tiles -> 400x24x24) through oracle/torch_twin.py "
-                  f"(torch {torch.__version__} CPU, {torch.get_num_threads()} threads), {el:.1f} s",
+        "value": 320 * 320 / best / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": "port",
+        "sample": f"best of {len(times)} after {warm} warm-up(s), each one 320x320 slice = 400 tiles -> 400x24x24 through "
+                  f"oracle/torch_twin.py (torch {torch.__version__} CPU, {torch.get_num_threads()} threads); best {best:.3f} s, "
+                  f"mean {sum(times) / len(times):.3f} s, {time.perf_counter() - t_begin:.1f} s in all",
     }
 
 
@@ -189,6 +197,12 @@ class TorchGroup:
         t = self.torch.tensor([v], dtype=self.torch.float64, device=self.device or "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def min(self, v):
+        return -self.max(-v)
+
+    def info(self):
+        return (self.dist.get_world_size(), self.dist.get_rank()) if self.world > 1 else (1, 0)
 
     def destroy(self):
         if self.world > 1:
@@ -259,13 +273,14 @@ def main():
     else:
         try:
             group = RcclGroup(model)      # communicator through the C ABI (no-op for one rank)
-            group.broadcast_weights(0, sd)  # load_state_dict on rank 0 only (sd is None elsewhere); one ncclBroadcast
         except Exception as exc:  # noqa: BLE001 -- keep the measurement alive if RCCL cannot come up on this node
             if world == 1:
                 raise
-            # Fallback, said out loud in the JSON line: the weights are synthetic and seeded, so every rank can build
-            # its own copy (the broadcast is outside the timed region anyway); barrier and MAX go over gloo on the CPU.
-            # No torch.cuda call is made: the process keeps its one HIP runtime.
+            # The bootstrap is collective: it fails on every rank (or rank 0's status blob says it could not make the
+            # unique id), so all ranks take this branch together.  Fallback, said out loud in the JSON line
+            # ("collective_fallback": true): the weights are synthetic and seeded, so every rank builds its own copy
+            # (the broadcast is outside the timed region anyway); barrier and MAX go over gloo on the CPU.  No
+            # torch.cuda call is made: the process keeps its one HIP runtime.
             print(f"[rank {rank}] RCCL through the C ABI failed ({exc}); falling back to seeded weights + gloo",
                   file=sys.stderr, flush=True)
             backend = "gloo-fallback"
@@ -273,8 +288,24 @@ def main():
             sd = syn.make_state_dict(seed=7, dim_hidden=H, num_layers=L, latent_dim=Z, **kw)
             model.load_state_dict(sd)
             model.to(f"cuda:{dev}")
+        else:
+            # load_state_dict on rank 0 only (sd is None elsewhere); ONE ncclBroadcast of the blob.  A failure past the
+            # bootstrap is fatal on purpose: a rank that fell back alone would leave the others inside the collective.
+            group.broadcast_weights(0, sd)
         model.eval()
     lib, h = model._lib, model._h
+    comm_ranks, comm_rank = group.info()
+    if world > 1 and (comm_ranks, comm_rank) != (world, rank):
+        raise SystemExit(f"[rank {rank}] the communicator reports rank {comm_rank} of {comm_ranks}, the launcher {rank} of {world}")
+    # Every rank evaluates the SAME 16 tiles with the weights it ended up with; the bit patterns of the outputs are
+    # summed and MAX / MIN-reduced: equal <=> every rank holds the weights rank 0 loaded (a wrong blob on a receiving
+    # rank would otherwise be silent -- nothing else in the benchmark compares ranks).
+    probe_tiles = np.random.default_rng(4242).random((16, 32, 32), dtype=np.float32)
+    probe_sum = float(np.ascontiguousarray(model(probe_tiles)).view(np.uint32).astype(np.float64).sum())
+    sum_max, sum_min = group.max(probe_sum), group.min(probe_sum)
+    if sum_max != sum_min:
+        raise SystemExit(f"[rank {rank}] ranks disagree on the probe output (checksum {probe_sum:.0f}, max {sum_max:.0f}, "
+                         f"min {sum_min:.0f}): the weight broadcast did not replicate rank 0's state_dict")
 
     # ---- synthetic input: slice k = default_rng(1000+k).random((320,320)), tiled 32/16 on the device ----
     if args.total_slices:
@@ -401,6 +432,8 @@ def main():
         "value": value, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": dtype, "dtype_note": dtype_note, "data": "synthetic",
+        # true = RCCL could not come up on this node and the ranks fell back to seeded weights + gloo plumbing
+        "collective_fallback": backend == "gloo-fallback",
         "config": {
             "workload": f"{workload_label(args, deep, n_total, world)}; per step {n_total} slice(s) = {n_total * 400} tiles 32x32 "
                         f"over {world} GPU(s); {stage}",
@@ -413,13 +446,21 @@ def main():
                         "gloo": "torch.distributed gloo (rehearsal: ranks may share a card)",
                         "gloo-fallback": "RCCL init failed on this node: seeded weights on every rank, barrier/MAX over gloo"}[backend]
                        if world > 1 else "single process",
+            # the communicator as the library reports it (msiren_comm_info / torch.distributed), the collective
+            # library behind it, and the cross-rank check of the replicated weights (see above)
+            "rccl_ranks": comm_ranks if backend in ("rccl", "nccl") else None,
+            "comm_ranks": comm_ranks,
+            "rccl_lib": (os.environ.get("MSIREN_RCCL_LIB") or "system librccl") if backend == "rccl" and world > 1 else None,
+            "ranks_hold_identical_weights": bool(sum_max == sum_min), "probe_checksum": probe_sum,
             "warmup_steps_run": warm_steps,
         },
         "roofline": {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "traffic": traffic_bytes(kernel), "kernel": kernel,
             # achieved HBM/fabric rate of the kernel, to show how far from the 8 TB/s roof it is
-            "hbm_gb_s": (traffic_bytes(kernel) / trunk_avg_s / 1e9) if (traffic_bytes(kernel) and trunk_avg_s > 0 and n_sl == 1) else None,
+            # (only where the committed PMC profile applies: a full 400-tile single-slice launch of the forward pipeline)
+            "hbm_gb_s": (traffic_bytes(kernel) / trunk_avg_s / 1e9)
+                        if (traffic_bytes(kernel) and trunk_avg_s > 0 and n_sl == 1 and evaluated == 400 and args.pipeline == "forward") else None,
             "hbm_peak_gb_s": 8000.0,
             "flops_per_launch": flops_launch, "avg_launch_ms": trunk_avg_s * 1e3, "launches": int(launches.value),
             "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -434,6 +475,15 @@ def main():
                     "kernel issues 3x that many fp16 MFMA FLOPs, hence peak = 2500/3",
         },
         "device_ms_per_step": dev_ms.value / args.steps,
+    }
+    # The same figure for the mode `value` is measured in: with two streams the trunk launches of consecutive steps
+    # overlap, so what describes the timed region is the rate at which whole slices leave the pipeline (encoder and
+    # modulator included in the time, only the trunk's algorithmic FLOPs counted), not one launch's duration.
+    tm_achieved = result["roofline"]["pipelined_tflops_per_gpu"]
+    result["roofline_timed_mode"] = {
+        "bound": "mfma", "achieved": tm_achieved, "peak": peak, "unit": "TFLOP/s", "frac": tm_achieved / peak,
+        "streams": args.streams, "kernel": kernel.replace(",4,", ",3,") if args.streams > 1 and dtype == "f16x3" else kernel,
+        "measured": "trunk FLOPs of the timed region / its wall time (MAX over ranks), per GPU: the figure consistent with `value`",
     }
 
     if rank == 0:

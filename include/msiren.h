@@ -118,6 +118,19 @@ MSIREN_API int msiren_get_tensor(msiren_handle h, const char* name, float* host_
  * required by msiren_forward_latent / msiren_forward_tiles. */
 MSIREN_API int msiren_commit_weights(msiren_handle h);
 
+/* The whole state_dict as ONE flat float32 image ("blob": mri_inr_amd/csrc/weights_blob.h) -- what
+ * torch.save / torch.load of the state_dict is to the reference (test_mod_siren.py:116-118) and the exact
+ * payload msiren_broadcast_weights sends: header (magic, version, key count, layout hash, payload size),
+ * one presence flag per key of the configuration, then every tensor (absent ones as zeros).
+ *   msiren_weights_blob_size   number of floats of this configuration's blob
+ *   msiren_weights_export      the tensors the handle holds -> blob_host (n_floats must be the blob size)
+ *   msiren_weights_import      blob -> the handle's tensors (replacing them; keys absent in the blob stay absent)
+ *                              and commit, exactly what a receiving rank of msiren_broadcast_weights executes.
+ * A blob of another configuration is MSIREN_E_SHAPE, a corrupt one MSIREN_E_INVALID; the handle keeps its tensors. */
+MSIREN_API int msiren_weights_blob_size(msiren_handle h, size_t* n_floats);
+MSIREN_API int msiren_weights_export(msiren_handle h, float* blob_host, size_t n_floats);
+MSIREN_API int msiren_weights_import(msiren_handle h, const float* blob_host, size_t n_floats);
+
 /* ---- forward ---------------------------------------------------------------------------------- */
 
 /* SirenNet.forward over the fixed grid (modulated_siren.py:215-233 + :448-455):

@@ -61,6 +61,9 @@ PROTOTYPES = {
     "msiren_set_tensor": (C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t]),
     "msiren_get_tensor": (C.c_int, [_vp, C.c_char_p, _vp, C.c_size_t]),
     "msiren_commit_weights": (C.c_int, [_vp]),
+    "msiren_weights_blob_size": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
+    "msiren_weights_export": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "msiren_weights_import": (C.c_int, [_vp, _vp, C.c_size_t]),
     "msiren_forward_mods": (C.c_int, [_vp, _vp, _i64, _vp]),
     "msiren_forward_mods_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
     "msiren_forward_latent": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),

@@ -23,6 +23,7 @@
 #include "../../include/msiren.h"
 #include "encoder_modulator.hip.h"
 #include "pass_queue.h"
+#include "weights_blob.h"
 #include "siren_trunk_f16x3.hip.h"
 #include "siren_trunk_f16x3n.hip.h"
 #include "siren_trunk_f16x3h.hip.h"
@@ -1075,36 +1076,23 @@ int need_rccl(Rccl** out) {
             return fail(MSIREN_E_HIP, "%s failed: %s (%s:%d)", #expr, (r_)->GetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-// Flat image of the state_dict for the broadcast: [one presence flag per expected key][every expected tensor],
-// keys in the (sorted) order of `expected`; absent tensors travel as zeros and stay absent on the receivers.
-size_t bcast_elems(msiren_ctx* h) {
-    size_t n = h->expected.size();
-    for (auto& kv : h->expected) n += kv.second;
-    return n;
-}
+// Flat image of the state_dict (weights_blob.h): header + one presence flag per expected key + every expected tensor.
+// msiren_weights_export / _import hand it to the caller; msiren_broadcast_weights sends it through one ncclBroadcast and
+// every receiving rank goes through import_blob() -- the same code a single-card test can drive.
+size_t bcast_elems(msiren_ctx* h) { return msiren::blob_elems(h->expected); }
 
 void bcast_pack(msiren_ctx* h, std::vector<float>& flat) {
-    flat.assign(bcast_elems(h), 0.f);
-    size_t i = 0, off = h->expected.size();
-    for (auto& kv : h->expected) {
-        auto it = h->tensors.find(kv.first);
-        if (it != h->tensors.end()) {
-            flat[i] = 1.f;
-            std::copy(it->second.begin(), it->second.end(), flat.begin() + off);
-        }
-        ++i;
-        off += kv.second;
-    }
+    flat.resize(bcast_elems(h));
+    msiren::blob_pack(h->expected, h->tensors, flat.data());
 }
 
-void bcast_unpack(msiren_ctx* h, const std::vector<float>& flat) {
-    size_t i = 0, off = h->expected.size();
-    h->tensors.clear();
-    for (auto& kv : h->expected) {
-        if (flat[i] != 0.f) h->tensors[kv.first].assign(flat.begin() + off, flat.begin() + off + kv.second);
-        ++i;
-        off += kv.second;
-    }
+// blob -> tensors of the handle (replacing what it held) -> commit
+int import_blob(msiren_ctx* h, const float* flat, size_t n) {
+    std::string err;
+    const int rc = msiren::blob_unpack(h->expected, flat, n, h->tensors, &err);
+    if (rc) return fail(rc == -3 || rc == -1 ? MSIREN_E_SHAPE : MSIREN_E_INVALID, "%s", err.c_str());
+    h->committed = false;
+    return msiren_commit_weights(h);
 }
 
 }  // namespace
@@ -1742,11 +1730,11 @@ static int broadcast_weights_group(msiren_handle* hs, int n, int32_t root) {
             flat.resize(elems);
             HIPCHK(hipMemcpyAsync(flat.data(), h->ws_comm.p, elems * sizeof(float), hipMemcpyDeviceToHost, h->sc[0].s));
             HIPCHK(hipStreamSynchronize(h->sc[0].s));
-            bcast_unpack(h, flat);
+            if ((rc = import_blob(h, flat.data(), flat.size()))) return rc;  // unpack + commit
         } else {
             HIPCHK(hipStreamSynchronize(h->sc[0].s));
+            if ((rc = msiren_commit_weights(h))) return rc;
         }
-        if ((rc = msiren_commit_weights(h))) return rc;
     }
     return 0;
 }
@@ -1761,6 +1749,28 @@ int msiren_broadcast_weights_all(msiren_handle* hs, int32_t n, int32_t root) {
     for (int i = 0; i < n; ++i)
         if (!hs[i]) return fail(MSIREN_E_INVALID, "null handle %d", i);
     return broadcast_weights_group(hs, n, root);
+}
+
+int msiren_weights_blob_size(msiren_handle h, size_t* n_floats) {
+    if (!h || !n_floats) return fail(MSIREN_E_INVALID, "null argument");
+    *n_floats = bcast_elems(h);
+    return 0;
+}
+
+int msiren_weights_export(msiren_handle h, float* blob_host, size_t n_floats) {
+    if (!h || !blob_host) return fail(MSIREN_E_INVALID, "null argument");
+    if (n_floats != bcast_elems(h))
+        return fail(MSIREN_E_SHAPE, "blob buffer holds %zu floats, this configuration's blob has %zu (msiren_weights_blob_size)", n_floats, bcast_elems(h));
+    msiren::blob_pack(h->expected, h->tensors, blob_host);
+    return 0;
+}
+
+int msiren_weights_import(msiren_handle h, const float* blob_host, size_t n_floats) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (!blob_host) return fail(MSIREN_E_INVALID, "null argument");
+    if ((rc = sync_all(h))) return rc;
+    return import_blob(h, blob_host, n_floats);
 }
 
 int msiren_comm_allreduce_max_f64(msiren_handle h, double* inout, int32_t n) {

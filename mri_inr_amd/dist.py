@@ -114,11 +114,25 @@ class RcclGroup:
         model._ensure_handle()
         self._lib, self._h = model._lib, model._h
         if self.world > 1:
-            uid = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            # Rank 0 ALWAYS serves a status blob -- the unique id, or an error marker when it could not make one
+            # (librccl missing, ...): every rank then leaves this constructor the same way and at once, instead of the
+            # peers waiting out the rendezvous timeout for an id that will never come.
+            payload = None
             if self.rank == 0:
-                _lib.check(self._lib.msiren_comm_unique_id(uid, _lib.COMM_ID_BYTES))
-            blob = exchange_from_rank0(bytes(uid.raw) if self.rank == 0 else None, env=env)
+                uid = C.create_string_buffer(_lib.COMM_ID_BYTES)
+                rc = self._lib.msiren_comm_unique_id(uid, _lib.COMM_ID_BYTES)
+                payload = b"OK:" + bytes(uid.raw) if rc == 0 else b"ER:" + _lib.last_error().encode("utf-8", "replace")
+            blob = exchange_from_rank0(payload, env=env)
+            if blob[:3] != b"OK:":
+                raise _lib.MsirenError("rank 0 could not create the RCCL unique id: " + blob[3:].decode("utf-8", "replace"))
+            blob = blob[3:]
             _lib.check(self._lib.msiren_comm_init_rank(self._h, blob, len(blob), self.world, self.rank))
+
+    def info(self) -> tuple[int, int]:
+        """(ranks, rank) of the communicator as the LIBRARY sees it (msiren_comm_info): (1, 0) without one."""
+        n, r = C.c_int32(), C.c_int32()
+        self._lib.msiren_comm_info(self._h, C.byref(n), C.byref(r))
+        return int(n.value), int(r.value)
 
     def broadcast_weights(self, src: int = 0, state_dict=None):
         """load_state_dict on ``src`` only (pass the state_dict there, None elsewhere); every rank ends up with the
@@ -148,6 +162,9 @@ class RcclGroup:
         v = (C.c_double * 1)(float(value))
         _lib.check(self._lib.msiren_comm_allreduce_max_f64(self._h, v, 1))
         return float(v[0])
+
+    def min(self, value: float) -> float:
+        return -self.max(-float(value))
 
     def destroy(self):
         from . import _lib

@@ -115,36 +115,59 @@ def spawn_ranks(argv: list[str], world: int, *, timeout: float | None = None, en
 
 # ---- rendezvous of a small blob (the 128-byte RCCL unique id) ------------------------------------------------
 
+def _recv_exact(conn, n: int) -> bytes:
+    buf = b""
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            raise OSError("peer closed the connection")
+        buf += chunk
+    return buf
+
+
 def _exchange_socket(payload: bytes | None, rank: int, world: int, addr: str, port: int, timeout: float) -> bytes:
-    """Rank 0 serves ``payload`` on (addr, port) to the other world-1 ranks; they connect with retry."""
+    """Rank 0 serves ``payload`` on (addr, port) until every one of the other world-1 ranks has ACKNOWLEDGED it; they
+    connect with retry.  Wire format: peer -> its rank (4 bytes); rank 0 -> length (4 bytes) + payload; peer -> one
+    ack byte.  A peer whose read came up short simply connects again: rank 0 counts acknowledged ranks, not accepted
+    connections, so a retry never uses up another rank's turn."""
     deadline = time.monotonic() + timeout
     if rank == 0:
         assert payload is not None
+        served = set()
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, port))
-            srv.listen(world)
-            for _ in range(world - 1):
-                srv.settimeout(max(0.1, deadline - time.monotonic()))
-                conn, _ = srv.accept()
+            srv.listen(max(world, 8))
+            while len(served) < world - 1:
+                left = deadline - time.monotonic()
+                if left <= 0:
+                    raise TimeoutError(f"rank 0: only ranks {sorted(served)} of {world - 1} peers fetched the rendezvous blob "
+                                       f"within {timeout:.0f} s")
+                srv.settimeout(max(0.1, left))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
                 with conn:
-                    conn.sendall(len(payload).to_bytes(4, "little") + payload)
+                    try:
+                        conn.settimeout(10.0)
+                        peer = int.from_bytes(_recv_exact(conn, 4), "little")
+                        conn.sendall(len(payload).to_bytes(4, "little") + payload)
+                        if _recv_exact(conn, 1) == b"\x06" and 0 < peer < world:
+                            served.add(peer)
+                    except OSError:
+                        pass  # that peer will come back
         return payload
     last = None
     while time.monotonic() < deadline:
         try:
-            with socket.create_connection((addr, port), timeout=max(0.1, deadline - time.monotonic())) as c:
-                buf = b""
-                while len(buf) < 4 or len(buf) < 4 + int.from_bytes(buf[:4], "little"):
-                    chunk = c.recv(65536)
-                    if not chunk:
-                        break
-                    buf += chunk
-                n = int.from_bytes(buf[:4], "little")
-                if len(buf) == 4 + n:
-                    return buf[4:]
-                last = OSError("short read from rank 0")
-        except OSError as e:  # rank 0 is not listening yet
+            with socket.create_connection((addr, port), timeout=max(0.1, min(10.0, deadline - time.monotonic()))) as c:
+                c.sendall(int(rank).to_bytes(4, "little"))
+                n = int.from_bytes(_recv_exact(c, 4), "little")
+                buf = _recv_exact(c, n)
+                c.sendall(b"\x06")
+                return buf
+        except OSError as e:  # rank 0 is not listening yet, or a short read: try again
             last = e
         time.sleep(0.05)
     raise TimeoutError(f"rank {rank}: no rendezvous with rank 0 at {addr}:{port} within {timeout:.0f} s ({last})")

@@ -188,17 +188,42 @@ class ModulatedSiren:
             _lib.check(self._lib.msiren_set_tensor(self._h, k.encode(), a.ctypes.data, a.size))
         self._committed = False
 
-    def _pull_tensors(self):
-        """Refresh the host mirror from the tensors the handle holds (after msiren_broadcast_weights)."""
+    def _pull_tensors(self, drop_absent: bool = False):
+        """Refresh the host mirror from the tensors the handle holds (after msiren_broadcast_weights / _import)."""
         self._ensure_handle()
         for k, v in list(self._sd.items()):
             a = np.empty(v.shape, dtype=np.float32)
             rc = self._lib.msiren_get_tensor(self._h, k.encode(), a.ctypes.data, a.size)
             if rc == _lib.E_STATE:  # the source rank did not hold it (e.g. no encoder)
+                if drop_absent and k != "grid":  # (the library rebuilds a missing grid buffer; the mirror keeps its own)
+                    del self._sd[k]
                 continue
             _lib.check(rc)
             self._sd[k] = a
         self.grid = self._sd["grid"]
+
+    def export_weights(self) -> np.ndarray:
+        """The state_dict as ONE flat float32 blob (msiren_weights_export): the payload of the multi-GPU weight
+        broadcast, and what a host ships when it moves the weights itself."""
+        self._ensure_handle()
+        if not self._committed:
+            self._push_tensors()
+        n = C.c_size_t()
+        _lib.check(self._lib.msiren_weights_blob_size(self._h, C.byref(n)))
+        blob = np.empty(n.value, dtype=np.float32)
+        _lib.check(self._lib.msiren_weights_export(self._h, blob.ctypes.data, blob.size))
+        return blob
+
+    def import_weights(self, blob: np.ndarray):
+        """blob -> this model's tensors (replacing them) -> commit: exactly what a receiving rank of
+        msiren_broadcast_weights executes (msiren_weights_import).  Keys the blob does not carry (e.g. a trunk-only
+        source without encoder) are dropped from ``state_dict()``, as they are on the device."""
+        self._ensure_handle()
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        _lib.check(self._lib.msiren_weights_import(self._h, blob.ctypes.data, blob.size))
+        self._committed = True
+        self._pull_tensors(drop_absent=True)
+        return self
 
     def _ensure_committed(self):
         self._ensure_handle()

@@ -1,6 +1,8 @@
 """Multi-GPU plumbing on the one card of the GPU box: RCCL through the C ABI (include/msiren.h, "multi-GPU") with a
 communicator of one rank, and bench.py starting its own ranks (gloo lets two ranks share the card).  The 2-rank
 logic of partition / broadcast is covered on the CPU in test_dist_gloo.py and test_launch.py."""
+import ctypes as C
+import io
 import json
 import os
 import subprocess
@@ -124,6 +126,147 @@ def test_commit_without_the_grid_buffer(prec):
     assert np.array_equal(b(tiles), want)
 
 
+def _model_kwargs(**over):
+    kw = dict(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0, use_bias=True,
+              dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None, outer_patch_size=32, inner_patch_size=16,
+              siren_patch_size=24, device="cuda:0", activation="sine")
+    kw.update(over)
+    return kw
+
+
+def test_weights_blob_export_import_is_the_receive_side_of_the_broadcast():
+    """handle A (loaded) -> msiren_weights_export -> handle B (fresh, same configuration) -> msiren_weights_import:
+    unpack + commit, the very code a non-root rank of msiren_broadcast_weights runs.  state_dict equal, outputs bit-equal;
+    a trunk-only source (no encoder keys) leaves the receiver without an encoder; blobs of another model are refused."""
+    from mri_inr_amd import ModulatedSiren, _lib, synthetic as syn
+
+    sd = syn.make_state_dict(seed=21, trained_like=True)
+    tiles = np.random.default_rng(2).random((9, 32, 32), dtype=np.float32)
+    a = ModulatedSiren(**_model_kwargs())
+    a.load_state_dict(sd)
+    want = a.to("cuda:0")(tiles)
+    blob = a.export_weights()
+    assert blob.dtype == np.float32 and blob[:1].view(np.uint32)[0] == 0x4257534D   # "MSWB"
+
+    b = ModulatedSiren(**_model_kwargs())          # fresh: holds its own random weights
+    assert not np.array_equal(b.to("cuda:0")(tiles), want)
+    b.import_weights(blob)
+    got_sd = b.state_dict()
+    assert set(got_sd) == set(sd)
+    for k in sd:
+        assert np.array_equal(got_sd[k], sd[k]), k
+    assert np.array_equal(b(tiles), want)
+    assert np.array_equal(b.export_weights(), blob)  # and it re-exports the same image
+
+    # source without encoder keys: the receiver ends up without them (forward_latent works, forward raises)
+    c = ModulatedSiren(**_model_kwargs())
+    for k, v in sd.items():
+        if not k.startswith("encoder."):
+            v = np.ascontiguousarray(v, np.float32)
+            _lib.check(c._lib.msiren_set_tensor(c._h, k.encode(), v.ctypes.data, v.size))
+    n = C.c_size_t()
+    _lib.check(c._lib.msiren_weights_blob_size(c._h, C.byref(n)))
+    part = np.empty(n.value, np.float32)
+    _lib.check(c._lib.msiren_weights_export(c._h, part.ctypes.data, part.size))
+    d = ModulatedSiren(**_model_kwargs())
+    d.import_weights(part)
+    assert not any(k.startswith("encoder.") for k in d.state_dict())
+    z = np.random.default_rng(3).standard_normal((4, 256)).astype(np.float32)
+    assert np.array_equal(d.forward_latent(z), a.forward_latent(z))
+    with pytest.raises(_lib.MsirenError, match="encoder"):
+        d(tiles)
+
+    # refusals leave the receiver as it was
+    e = ModulatedSiren(**_model_kwargs(num_layers=4))
+    before = e.to("cuda:0")(tiles)
+    with pytest.raises(RuntimeError):
+        e.import_weights(blob)                      # another depth: MSIREN_E_SHAPE
+    bad = blob.copy()
+    bad[0] = 1.0
+    with pytest.raises(ValueError):
+        b.import_weights(bad)                       # not a blob: MSIREN_E_INVALID
+    assert np.array_equal(e(tiles), before) and np.array_equal(b(tiles), want)
+    assert c._lib.msiren_weights_export(c._h, part.ctypes.data, part.size - 1) == _lib.E_SHAPE
+
+
+def _build_rccl_stub(tmp_path):
+    """tests/stubs/rccl_stub.cpp -> librccl_stub.so (host code only; links the HIP runtime libmsiren links)."""
+    out = os.path.join(str(tmp_path), "librccl_stub.so")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        os.path.join(ROOT, "tests", "stubs", "rccl_stub.cpp"), "-o", out, "-L/opt/rocm/lib", "-lamdhip64"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+TWO_RANK_WORKER = """
+    import os, sys, numpy as np
+    from mri_inr_amd import ModulatedSiren, _lib, synthetic as syn
+    from mri_inr_amd.dist import RcclGroup
+    rank = int(os.environ["RANK"])
+    no_encoder = os.environ.get("DROP_ENCODER") == "1"
+    sd = syn.make_state_dict(seed=33, trained_like=True)          # what rank 0 loads; the others only use it to check
+    m = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda:0", activation="sine")
+    g = RcclGroup(m)
+    assert g.info() == (2, rank), g.info()
+    if rank == 0 and no_encoder:
+        for k in list(m._sd):                                     # a trunk + modulator source: nothing pushed yet
+            if k.startswith("encoder."):
+                del m._sd[k]
+            else:
+                m._sd[k] = sd[k]
+        g.broadcast_weights(0, None)
+    else:
+        g.broadcast_weights(0, sd if rank == 0 else None)         # rank 1: receive -> unpack -> commit
+    have = m.state_dict()
+    for k, v in sd.items():
+        if no_encoder and k.startswith("encoder."):
+            continue
+        assert np.array_equal(have[k], v), (rank, k)
+    z = np.random.default_rng(5).standard_normal((6, 256)).astype(np.float32)
+    out = m.forward_latent(z)
+    if not no_encoder:
+        tiles = np.random.default_rng(6).random((6, 32, 32), dtype=np.float32)
+        out = np.concatenate([out, m(tiles)])
+    cs = float(out.view(np.uint32).astype(np.float64).sum())
+    assert g.max(cs) == cs and g.min(cs) == cs, (rank, cs)         # both ranks computed the same bits
+    g.barrier()
+    g.destroy()
+    assert "torch" not in sys.modules
+    print(f"RANK{rank} OK {cs:.0f}", flush=True)
+"""
+
+
+@pytest.mark.parametrize("drop_encoder", ["0", "1"])
+def test_two_ranks_on_one_card_broadcast_receive_path_through_a_stub_rccl(tmp_path, drop_encoder):
+    """RCCL proper refuses two ranks on one device, so the 1-GPU box runs the two-rank path of dist.RcclGroup /
+    msiren_broadcast_weights against tests/stubs/rccl_stub.cpp (file-carried collectives, same C signatures, device
+    pointers): rank 1 executes the receive branch for real -- blob D2H, unpack, commit -- and must end up with rank 0's
+    state_dict and bit-identical outputs."""
+    stub = _build_rccl_stub(tmp_path)
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent(TWO_RANK_WORKER))
+    env = {k: v for k, v in os.environ.items() if k not in launch.ENV_KEYS}
+    env.update({"MSIREN_RCCL_LIB": stub, "RCCL_STUB_DIR": str(tmp_path), "PYTHONPATH": ROOT, "DROP_ENCODER": drop_encoder})
+    out, err = io.StringIO(), io.StringIO()
+    rc, rank0 = launch.spawn_ranks([sys.executable, str(script)], 2, timeout=300, env=env, stdout=out, stderr=err)
+    assert rc == 0, out.getvalue()[-2000:] + err.getvalue()[-4000:]
+    assert "RANK0 OK" in rank0 and "RANK1 OK" in err.getvalue()
+
+
+def test_bench_two_ranks_rehearsal_reports_what_the_communicator_saw(tmp_path):
+    """bench.py --gpus 2 on the one card through the stub: the line carries the communicator's own rank count, no
+    fallback, and the cross-rank check of the replicated weights."""
+    stub = _build_rccl_stub(tmp_path)
+    d = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+               {"MSIREN_BENCH_ALLOW_SHARED": "1", "MSIREN_RCCL_LIB": stub, "RCCL_STUB_DIR": str(tmp_path)}, timeout=400)
+    assert d["n_gpus"] == 2 and d["collective_fallback"] is False
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["rccl_lib"] == stub
+    assert d["config"]["ranks_hold_identical_weights"] is True
+
+
 def _bench(args, env=None, timeout=900):
     e = {k: v for k, v in os.environ.items() if k not in launch.ENV_KEYS}
     e.update(env or {})
@@ -145,6 +288,10 @@ def test_bench_single_gpu_line_carries_roofline_cpu_baseline_and_extras():
     assert rf["bound"] == "mfma" and rf["launches"] >= 200 and 0.2 < rf["frac"] < 1.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert "best of" in d["cpu_baseline"]["sample"]
+    assert d["collective_fallback"] is False and d["config"]["comm_ranks"] == 1
+    tm = d["roofline_timed_mode"]
+    assert tm["streams"] == 2 and abs(tm["achieved"] - rf["pipelined_tflops_per_gpu"]) < 1e-9 and 0.2 < tm["frac"] < 1.0
     ex = d["extra"]
     assert 0 < ex["host_to_host_mpixel_s"] < d["value"] * 1.05   # PCIe-inclusive: never faster than device-resident
     assert ex["reconstruct_mpixel_s"] > 0
@@ -171,6 +318,8 @@ def test_bench_two_rccl_ranks_on_one_card_rendezvous_then_fall_back():
     d = _bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"], {"MSIREN_BENCH_ALLOW_SHARED": "1"},
                timeout=400)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["collective_fallback"] is True and d["config"]["rccl_ranks"] is None and d["config"]["comm_ranks"] == 2
+    assert d["config"]["ranks_hold_identical_weights"] is True
     assert "RCCL init failed" in d["config"]["backend"]
     assert abs(d["value"] - 2 * 320 * 320 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
 

@@ -7,6 +7,7 @@ import os
 import subprocess
 import sys
 import textwrap
+import time
 
 import pytest
 
@@ -96,3 +97,41 @@ def test_bench_gpus2_without_a_launcher_starts_two_ranks():
     assert "[launch] rank 0 of 2 started" in r.stderr and "[launch] rank 1 of 2 started" in r.stderr
     assert "needs a gfx950 GPU" in r.stderr
     assert "n_gpus" not in r.stdout
+
+
+def test_rendezvous_serves_until_every_rank_has_acknowledged():
+    """A peer whose connection dies mid-payload comes back: rank 0 counts acknowledged RANKS, not accepted connections,
+    so the retry does not use up the turn of the last rank (round-2 advice: it used to time out after 300 s)."""
+    import socket
+    import threading
+
+    port = launch.free_port()
+    payload = bytes(range(200))
+    got = {}
+
+    def serve():
+        got[0] = launch._exchange_socket(payload, 0, 3, "127.0.0.1", port, 30.0)
+
+    def peer(rank):
+        got[rank] = launch._exchange_socket(None, rank, 3, "127.0.0.1", port, 30.0)
+
+    t0 = threading.Thread(target=serve)
+    t0.start()
+    # rank 1's first attempt: connects, announces itself, reads 10 bytes and hangs up without the ack
+    deadline = time.monotonic() + 20
+    while True:
+        try:
+            with socket.create_connection(("127.0.0.1", port), timeout=2) as c:
+                c.sendall((1).to_bytes(4, "little"))
+                c.recv(10)
+            break
+        except OSError:
+            assert time.monotonic() < deadline
+            time.sleep(0.05)
+    peers = [threading.Thread(target=peer, args=(r,)) for r in (1, 2)]
+    for t in peers:
+        t.start()
+    for t in peers + [t0]:
+        t.join(40)
+        assert not t.is_alive()
+    assert got == {0: payload, 1: payload, 2: payload}
