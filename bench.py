@@ -412,10 +412,16 @@ def main():
         # MFMA peak / 3.  The fp32-MFMA peak the north star names is reported next to it.
         dtype, peak = "f16x3", F16_MFMA_PEAK_TFLOPS / 3.0
         dtype_note = "split-fp16: hi/lo fp16 operands, three fp16 MFMAs per product, fp32 accumulate; fp32-equivalent accuracy (1e-4 gate)"
+        act_i = 1 if args.activation == "morlet" else 0
         if os.environ.get("MSIREN_F16_TILE") == "32":   # A/B build (make AB32=1) with the 32x32x16 kernel selected
-            kernel = "siren_trunk_f16x3_kernel<%d,4>" % (1 if args.activation == "morlet" else 0)
+            kernel = "siren_trunk_f16x3_kernel<%d,4>" % act_i
+        elif 3 <= L <= 5 and os.environ.get("MSIREN_F16_WS", "1") != "0":
+            # single-stream launches (the roofline phase) run the weight-stationary trunk; with two streams the timed region
+            # runs the register-resident one beside the next call's encoder / modulator (roofline_timed_mode.kernel)
+            kernel = "siren_trunk_f16x3w_kernel<%d,4>" % act_i
         else:                                            # 16x16x32 tiles; the num_layers = 5 straight-line instance
-            kernel = "siren_trunk_f16x3n_kernel<%d,4,%d>" % (1 if args.activation == "morlet" else 0, 5 if L == 5 else 0)
+            kernel = "siren_trunk_f16x3n_kernel<%d,4,%d>" % (act_i, 5 if L == 5 else 0)
+        kernel_two_streams = "siren_trunk_f16x3n_kernel<%d,3,%d>" % (act_i, 5 if L == 5 else 0)
     elif args.precision in ("bf16", "f16"):
         dtype, peak = args.precision, F16_MFMA_PEAK_TFLOPS
         dtype_note = f"{args.precision} MFMA operands, fp32 accumulate"
@@ -424,6 +430,8 @@ def main():
         dtype, peak = "f32", FP32_MFMA_PEAK_TFLOPS
         dtype_note = "fp32 MFMA (exact fp32 products and accumulation)"
         kernel = "siren_trunk_f32_kernel<%d,%d,%d,0>" % (H, args.activation == "morlet", deep)
+    if dtype != "f16x3":
+        kernel_two_streams = kernel
     stage = ("slice -> tiles -> black filter -> encoder+modulator+fused trunk -> weighted fold -> slice, device-resident"
              if args.pipeline == "reconstruct" else
              f"ModulatedSiren.forward (encoder+modulator+fused trunk, {args.activation}) on resident tiles -> (B,24,24) in HBM")
@@ -467,8 +475,10 @@ def main():
             # tools/mfma_peak_probe.hip: all 256 CUs issuing only fp16 MFMAs sustain 1476 TFLOP/s under the
             # board power limit (profiles/r1/10_*); context for `frac`, which is against the nominal peak
             "sustained_fp16_mfma_tflops_measured": SUSTAINED_F16_MFMA_TFLOPS,
-            "measured": "HIP event pairs on the kernel's stream; single-stream phase of this run (kernel alone), rank 0"
-                        if args.streams > 1 else "HIP event pairs on the kernel's stream inside the timed region, rank 0",
+            "measured": ("HIP event pairs on the kernel's stream; single-stream phase of this run (kernel alone: what a handle with "
+                         "one stream launches), rank 0; the two-stream timed region launches " + kernel_two_streams +
+                         " (roofline_timed_mode)") if args.streams > 1 else
+                        "HIP event pairs on the kernel's stream inside the timed region, rank 0",
             "timed_region_avg_launch_ms": overlapped_trunk_ms, "timed_region_launches": n_over,
             "pipelined_tflops_per_gpu": model.flops_per_coord() * 576 * 400 * n_total * args.steps / elapsed / 1e12 / world,
             "note": "achieved = algorithmic FLOPs (525824 per coordinate at 256x5) / mean kernel time; for f16x3 the "
@@ -482,7 +492,7 @@ def main():
     tm_achieved = result["roofline"]["pipelined_tflops_per_gpu"]
     result["roofline_timed_mode"] = {
         "bound": "mfma", "achieved": tm_achieved, "peak": peak, "unit": "TFLOP/s", "frac": tm_achieved / peak,
-        "streams": args.streams, "kernel": kernel.replace(",4,", ",3,") if args.streams > 1 and dtype == "f16x3" else kernel,
+        "streams": args.streams, "kernel": kernel_two_streams if args.streams > 1 and dtype == "f16x3" else kernel,
         "measured": "trunk FLOPs of the timed region / its wall time (MAX over ranks), per GPU: the figure consistent with `value`",
     }
 

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "msiren_comm_destroy": (C.c_int, [_vp]),
     "msiren_trunk_timeline": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "msiren_f16x3_timeline": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "msiren_f16x3w_timeline": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
 }
 
 _lib = None

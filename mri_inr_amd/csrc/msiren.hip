@@ -27,6 +27,7 @@
 #include "siren_trunk_f16x3.hip.h"
 #include "siren_trunk_f16x3n.hip.h"
 #include "siren_trunk_f16x3h.hip.h"
+#include "siren_trunk_f16x3w.hip.h"
 #include "siren_trunk_f32.hip.h"
 #include "siren_trunk_x1.hip.h"
 #include "tiling.hip.h"
@@ -87,6 +88,9 @@ struct msiren_ctx {
     int f16_tile = 16;        // MFMA tile of the split-fp16 trunk in use
     int lds_attr_f16n[2][4] = {};
     int lds_attr_f16h[2][2] = {};  // half-unit instances (num_layers = 5 only)
+    int lds_attr_f16w[2] = {};     // weight-stationary instances ([activation])
+    float* d_dump = nullptr;       // 256 floats: where lanes of the weight-stationary trunk that have nothing to store write
+    int f16_ws = 1;                // the weight-stationary trunk runs single-stream launches (MSIREN_F16_WS=0: never; read at create)
     float *d_bias16 = nullptr, *d_wout16 = nullptr, *d_s0t = nullptr;
     float winv16[16] = {0};    // 32x32 kernel: exact inverse of each hidden layer's power-of-two weight scale
     float mscale16[16] = {0};  // 16x16 kernel: factor of each layer's modulation row (the NEXT layer's weight scale, inverted)
@@ -97,6 +101,12 @@ struct msiren_ctx {
     float winvx1[64] = {0};
     bool x1_ready = false;
     int num_cus = 256;
+    // diagnostic knobs ("Environment knobs"): read ONCE, at msiren_create -- not on the launch path
+    int cus_limit = 256;       // MSIREN_GRID: cap on the persistent grids
+    int ring_force = 0;        // MSIREN_F16_RING: 3 / 4 forces the weight ring depth of the register-resident trunk
+    int half_allowed = 1;      // MSIREN_F16_HALF=0: never use the half-unit instance
+    int host_chunks = 0;       // MSIREN_HOST_CHUNKS: chunks a synchronous host call cuts itself into (0 = default)
+    unsigned queue_start = 0;  // MSIREN_QUEUE_START: initial value of the never-reset pass counters
     int lds_attr_f16[2][2] = {};  // dynamic-LDS limit already raised for siren_trunk_f16x3_kernel<act, R> ([R == 4][act])
     // modulator: transposed weights so that consecutive threads read consecutive outputs
     float *d_modw = nullptr, *d_modb = nullptr, *d_modw_rm = nullptr;  // transposed / as stored (row-major)
@@ -613,8 +623,7 @@ int queue_for_launch(msiren_ctx* h, int64_t npasses, int** counter, unsigned* ba
         int rc = ensure(h, c.queue, 256);
         if (rc) return rc;
         // test knob: start the never-reset counter just below 2^32 (or 2^31) to exercise its wrap-around
-        unsigned start = 0;
-        if (const char* e = std::getenv("MSIREN_QUEUE_START")) start = (unsigned)std::strtoul(e, nullptr, 0);
+        const unsigned start = h->queue_start;
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c.queue.p, (int)start, 64, c.s));
         c.pq.reset(start);
     }
@@ -700,7 +709,70 @@ int launch_trunk_f16x3h_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int gr
     return 0;
 }
 
+// weight-stationary trunk (siren_trunk_f16x3w.hip.h): passes of 2..4 units, laid out by ws_schedule
+int launch_trunk_f16x3w(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
+    msiren::TrunkWsParams p{};
+    if (!h->d_dump) HIPCHK(hipMalloc((void**)&h->d_dump, 256 * sizeof(float)));
+    p.dump = h->d_dump;
+    p.s0t = h->d_s0t;
+    p.wp = (const _Float16*)h->d_wp16n;
+    p.bias = h->d_bias16;
+    p.wout = h->d_wout16;
+    p.mods = mods_dev;
+    p.out = out_dev;
+    for (int i = 0; i < 16; ++i) p.mscale[i] = h->mscale16[i];
+    p.bout = h->bout;
+    p.cg0 = h->cg0;
+    p.cg = h->cg;
+    p.B = (int)B;
+    p.P = h->P;
+    p.L = h->L;
+    p.plan = h->plan;
+    const int upp = (h->P + 31) / 32;
+    const int64_t units = B * upp;
+    if (units > 0x3fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
+    p.units_per_patch = upp;
+    p.unit_base = 0;
+    p.total_units = (int)units;
+    {   // unit / upp as a multiply-high: k = 30 + ceil(log2 upp), m = ceil(2^k / upp) (exact for units < 2^30)
+        int lg = 0;
+        while ((1 << lg) < upp) ++lg;
+        p.div_k = 30 + lg;
+        p.div_m = (unsigned)(((1ULL << p.div_k) + (unsigned)upp - 1) / (unsigned)upp);
+    }
+    // small batches: one pass of 2 units per workgroup (latency); otherwise one workgroup per CU
+    const int grid = (int)std::min<int64_t>(h->cus_limit, (units + 1) / 2);
+    const msiren::WsSchedule sch = msiren::ws_schedule(units, grid);
+    int rc = queue_for_launch(h, sch.npasses(), &p.pass_counter, &p.pass_base);
+    if (rc) return rc;
+    const int lds = msiren::WsLds<4>::total(h->L);
+    const bool mor = h->cfg.activation == MSIREN_ACT_MORLET;
+    using Kern = void (*)(msiren::TrunkWsParams);
+    const Kern k = mor ? (Kern)msiren::siren_trunk_f16x3w_kernel<1, 4> : (Kern)msiren::siren_trunk_f16x3w_kernel<0, 4>;
+    int& done = h->lds_attr_f16w[mor ? 1 : 0];
+    if (done < lds) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return queue_launched(h, fail(MSIREN_E_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e)));
+        done = lds;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
+    hipError_t e = hipGetLastError();
+    return queue_launched(h, e == hipSuccess ? 0 : fail(MSIREN_E_HIP, "trunk launch: %s", hipGetErrorString(e)));
+}
+
+// The weight-stationary trunk is the faster kernel on its own (it owns the whole register file and LDS of its CUs, so
+// nothing can run beside it); with two streams the register-resident trunk wins because the next call's encoder and
+// modulator run beside it.  Depths 3..5 (its unit images + tables must fit the LDS); modulation buffer below 4 GB.
+bool use_f16x3w(msiren_ctx* h, int64_t B) {
+    return h->f16_ws && h->nstreams == 1 && !h->overlap && h->L >= 3 && h->L <= 8 &&
+           msiren::WsLds<4>::total(h->L) <= 160 * 1024 && (int64_t)h->L * B * 256 * 4 < (1LL << 32);
+}
+
 int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
+    const int upp_ = (h->P + 31) / 32;
+    // (small batches of depth-5 models keep the half-unit instance: twice the waves, lower latency)
+    if (use_f16x3w(h, B) && !(h->L == 5 && h->half_allowed && !h->plan && B * upp_ <= 2 * (int64_t)h->cus_limit))
+        return launch_trunk_f16x3w(h, mods_dev, B, out_dev);
     msiren::TrunkF16Params p{};
     p.grid = h->d_grid;
     p.l0 = h->d_l0;
@@ -724,10 +796,9 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     // R = 3 leaves ~35 KB of LDS per CU free, enough for an encoder / modulator workgroup of the NEXT
     // call (other stream) to run beside the persistent trunk workgroup; R = 4 fills the CU.
     int ring = (h->nstreams > 1 || h->overlap) ? 3 : 4;
-    if (const char* e = std::getenv("MSIREN_F16_RING")) ring = std::atoi(e);
+    if (h->ring_force) ring = h->ring_force;
     const bool r4 = ring >= 4 && msiren::F16Lds<4>::total(h->L) <= 160 * 1024;
-    int cus = h->num_cus;
-    if (const char* e = std::getenv("MSIREN_GRID")) cus = std::max(1, std::min(cus, std::atoi(e)));  // experiment knob
+    const int cus = h->cus_limit;
 
     // One launch of a piece of the batch: units [base, base + count) of `per_wave` coordinates each.  The pass queue
     // (workgroup g starts with pass g, further passes come from the counter) is claimed per launch.
@@ -755,8 +826,7 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     // stream (event fork / join, no launch gap): 0.315 vs 0.289 ms.  A half-unit pass on an otherwise idle chip is not
     // half a round (its weight-fragment reads are those of a full unit; prologue and layer 0 do not shrink), and the
     // cross-stream dependency costs more than the tail it removes.
-    bool half_ok = h->f16_tile == 16 && !h->plan && h->L == 5;
-    if (const char* e = std::getenv("MSIREN_F16_HALF")) half_ok = half_ok && std::atoi(e) != 0;  // A/B knob
+    const bool half_ok = h->f16_tile == 16 && !h->plan && h->L == 5 && h->half_allowed;
     if (half_ok && units <= 2 * (int64_t)cus) return launch_piece(true, 0, B * ((h->P + 15) / 16));
     return launch_piece(false, 0, units);
 }
@@ -1146,6 +1216,13 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     h->O = cfg->outer_patch_size;
     h->I = cfg->inner_patch_size;
     h->num_cus = prop.multiProcessorCount;
+    h->cus_limit = h->num_cus;
+    if (const char* e = std::getenv("MSIREN_GRID")) h->cus_limit = std::max(1, std::min(h->num_cus, std::atoi(e)));
+    if (const char* e = std::getenv("MSIREN_F16_RING")) h->ring_force = std::atoi(e);
+    if (const char* e = std::getenv("MSIREN_F16_HALF")) h->half_allowed = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_HOST_CHUNKS")) h->host_chunks = std::max(1, std::min(std::atoi(e), 16));
+    if (const char* e = std::getenv("MSIREN_QUEUE_START")) h->queue_start = (unsigned)std::strtoul(e, nullptr, 0);
+    if (const char* e = std::getenv("MSIREN_F16_WS")) h->f16_ws = std::atoi(e) != 0;
     declare_expected(h);
     hipError_t e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->sc[0].s, hipStreamNonBlocking);
@@ -1171,7 +1248,7 @@ int msiren_destroy(msiren_handle h) {
     if (h->d_wp16n) (void)hipFree(h->d_wp16n);
     for (void* q : {h->d_wpx1, h->d_biasx1, h->d_woutx1})
         if (q) (void)hipFree(q);
-    float* ptrs[] = {h->d_l0last, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
+    float* ptrs[] = {h->d_dump, h->d_l0last, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
@@ -1299,7 +1376,7 @@ int msiren_forward_tiles(msiren_handle h, const float* tiles_host, int64_t B, fl
     // kernels, the first half's download beside the second half's trunk.  (More than two chunks do not help:
     // a pageable copy waits for its stream to drain.)  Patches are independent: the cut does not change results.
     int nchunks = B >= 256 ? 2 : 1;
-    if (const char* e = std::getenv("MSIREN_HOST_CHUNKS")) nchunks = std::max(1, std::min(std::atoi(e), 16));  // experiment knob
+    if (h->host_chunks) nchunks = h->host_chunks;
     nchunks = (int)std::min<int64_t>(nchunks, B);
     const int cur0 = h->cur;
     const size_t tile_elems = (size_t)h->O * h->O;
@@ -1636,6 +1713,47 @@ int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, flo
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(stamps_host, st.p, (size_t)grid * 4 * 48 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(st.p));
+    HIPCHK(hipFree(q.p));
+    return 0;
+}
+
+int msiren_f16x3w_timeline(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev, uint64_t* stamps_host) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (!h->f16x3_ready || h->cfg.activation != MSIREN_ACT_SINE || h->L < 3 || msiren::WsLds<4>::total(h->L) > 160 * 1024)
+        return fail(MSIREN_E_INVALID, "f16x3w timeline: H=256 sine model with 3 <= num_layers <= 5 required");
+    if (B <= 0 || !mods_dev || !out_dev || !stamps_host) return fail(MSIREN_E_INVALID, "bad arguments");
+    msiren::TrunkWsParams p{};
+    if (!h->d_dump) HIPCHK(hipMalloc((void**)&h->d_dump, 256 * sizeof(float)));
+    p.dump = h->d_dump;
+    p.s0t = h->d_s0t; p.wp = (const _Float16*)h->d_wp16n; p.bias = h->d_bias16; p.wout = h->d_wout16; p.mods = mods_dev; p.out = out_dev;
+    for (int i = 0; i < 16; ++i) p.mscale[i] = h->mscale16[i];
+    p.bout = h->bout; p.cg0 = h->cg0; p.cg = h->cg; p.B = (int)B; p.P = h->P; p.L = h->L;
+    const int upp = (h->P + 31) / 32;
+    p.units_per_patch = upp;
+    p.total_units = (int)(B * upp);
+    int lg = 0;
+    while ((1 << lg) < upp) ++lg;
+    p.div_k = 30 + lg;
+    p.div_m = (unsigned)(((1ULL << p.div_k) + (unsigned)upp - 1) / (unsigned)upp);
+    const int grid = (int)std::min<int64_t>(h->cus_limit, ((int64_t)p.total_units + 1) / 2);
+    DevBuf st, q;
+    const size_t nst = (size_t)grid * 96 * 4 * sizeof(uint64_t);
+    if ((rc = ensure(h, st, nst)) || (rc = ensure(h, q, 256))) return rc;
+    hipStream_t s = h->sc[h->cur].s;
+    HIPCHK(hipMemsetAsync(st.p, 0, nst, s));
+    p.pass_counter = (int*)q.p;
+    HIPCHK(hipMemsetAsync(p.pass_counter, 0, 4, s));
+    p.pass_base = 0;
+    p.stamps = (unsigned long long*)st.p;
+    const int lds = msiren::WsLds<4>::total(h->L);
+    auto k = msiren::siren_trunk_f16x3w_kernel<0, 4, 1>;
+    HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(stamps_host, st.p, nst, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipFree(st.p));
     HIPCHK(hipFree(q.p));

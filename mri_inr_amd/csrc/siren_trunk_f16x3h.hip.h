@@ -82,24 +82,24 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
 
     h8 Xh[8], Xl[8], Yh[8], Yl[8];  // B fragments [k-step]
     f32x4 acc[2][2];                // [tile parity][sub-tile]
-    float part = 0.f;
+    float part4[4] = {0.f, 0.f, 0.f, 0.f};  // last_layer dot product, four chains of 64 features (canonical order: f16x3n header)
 
     fp16x2 eh[2][2], el[2][2];      // [sub-tile][half]
-    f32x4 tb_m[2], tb_w[2], bia[2];
+    f32x4 tb_m[2], bia[2];
     auto tbl_load = [&](int sub, const unsigned char* ml, const unsigned char* wo, int t, bool withw) {
         const int fo = (32 * t + 16 * sub) * 4;
         tb_m[sub] = *reinterpret_cast<const f32x4*>(ml + fo);
-        if (withw) tb_w[sub] = *reinterpret_cast<const f32x4*>(wo + fo);
+        if (withw) tb_m[sub] *= *reinterpret_cast<const f32x4*>(wo + fo);  // final layer: modulation x last_layer.weight
     };
     auto bias_load = [&](int sub, const unsigned char* bl, int t) {
         bia[sub] = *reinterpret_cast<const f32x4*>(bl + (32 * t + 16 * sub) * 4);
         asm("; bias fragment stays in arch VGPRs" : "+v"(bia[sub]));
     };
-    auto epi_half = [&](const f32x4& a, float cgl, int sub, int hh, bool lastl, bool fresh = false) {
+    auto epi_half = [&](const f32x4& a, float cgl, int sub, int hh, bool lastl, bool fresh = false, int chain = 0, bool ready = false) {
         float v[2];
         if (fresh) {  // accumulator written by the MFMAs just before: builtins, hipcc pads the MFMA -> VALU hazard
-            v[0] = activate<ACT>(a[2 * hh], cgl);
-            v[1] = activate<ACT>(a[2 * hh + 1], cgl);
+            v[0] = ready ? a[2 * hh] : activate<ACT>(a[2 * hh], cgl);       // (ready: layer 0's table values)
+            v[1] = ready ? a[2 * hh + 1] : activate<ACT>(a[2 * hh + 1], cgl);
         } else if constexpr (ACT == 0) {
             asm volatile("v_sin_f32 %0, %1" : "=v"(v[0]) : "v"(a[2 * hh]));
             asm volatile("v_sin_f32 %0, %1" : "=v"(v[1]) : "v"(a[2 * hh + 1]));
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
         }
         if (lastl) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) part = __builtin_fmaf(v[e] * tb_m[sub][2 * hh + e], tb_w[sub][2 * hh + e], part);
+            for (int e = 0; e < 2; ++e) part4[chain] = __builtin_fmaf(v[e], tb_m[sub][2 * hh + e], part4[chain]);
         } else {
             split_products_pk(v[0], tb_m[sub][2 * hh], v[1], tb_m[sub][2 * hh + 1], eh[sub][hh], el[sub][hh]);
         }
@@ -152,13 +152,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
         if ((T) == 0) {                                                                       \
             if ((Q) == 0) tbl_load(1, mlp_, zeroB, 7, false);                                 \
             if ((Q) < 2) {                                                                    \
-                epi_half(acc[1][(Q) & 1], cgp_, (Q) & 1, 0, false, true);                     \
-                epi_half(acc[1][(Q) & 1], cgp_, (Q) & 1, 1, false, true);                     \
+                epi_half(acc[1][(Q) & 1], p.cg, (Q) & 1, 0, false, true, 0, l_ == 1);           \
+                epi_half(acc[1][(Q) & 1], p.cg, (Q) & 1, 1, false, true, 0, l_ == 1);           \
             }                                                                                 \
             if ((Q) == 2) epi_store(INh[7], INl[7]);                                          \
         } else {                                                                              \
             if ((Q) == 0) tbl_load(1, ml_, wo_, ((T) + 7) & 7, LASTF);                        \
-            if (((Q) & 1) == 0) epi_half(acc[((T) + 1) & 1][(Q) >> 2], p.cg, (Q) >> 2, ((Q) >> 1) & 1, LASTF); \
+            if (((Q) & 1) == 0) epi_half(acc[((T) + 1) & 1][(Q) >> 2], p.cg, (Q) >> 2, ((Q) >> 1) & 1, LASTF, false, (((T) + 7) & 7) >> 1); \
             if ((Q) == 7 && !(LASTF)) epi_store(OUTh[((T) + 7) & 7], OUTl[((T) + 7) & 7]);    \
         }                                                                                     \
         if ((Q) == 5) bias_load(0, (T) < 7 ? bl_ : bnx_, ((T) + 1) & 7);                      \
@@ -196,7 +196,6 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
         const unsigned char* bnx_ = (LASTF) ? biasB : biasB + l_ * 1024;                      \
         const unsigned char* ml_ = modB + l_ * 1024;                                          \
         const unsigned char* mlp_ = modB + (l_ - 1) * 1024;                                   \
-        const float cgp_ = l_ > 1 ? p.cg : p.cg0;                                             \
         MSIREN_H16_TILE(INh, INl, OUTh, OUTl, 0, LASTF);                                        \
         MSIREN_H16_TILE(INh, INl, OUTh, OUTl, 1, LASTF);                                        \
         MSIREN_H16_TILE(INh, INl, OUTh, OUTl, 2, LASTF);                                        \
@@ -236,9 +235,9 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
             *reinterpret_cast<f32x4*>(modT + l * 256 + lane * 4) = m * mscaleT[l];
         }
         if (tid == 0) qslot[(pass + 1) & 1] = nxt;
-        const float2 xy0 = reinterpret_cast<const float2*>(p.grid)[pc0];
 
-        // layer 0 from the table, k-steps 0..6; the last 32 features stay sine arguments in acc[1]
+        // layer 0 from the table: k-steps 0..6 finished here, the last 32 features wait in acc[1] for the first hidden
+        // layer's pending-epilogue slot (see the 32-coordinate kernel)
         const f32x4* s0a = reinterpret_cast<const f32x4*>(p.s0t) + (size_t)q * p.P + pc0;
         f32x4 raw[7][2];
 #pragma unroll
@@ -259,18 +258,10 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
             Xl[s] = to_acc_file(pack_h8(ll[0][0], ll[0][1], ll[1][0], ll[1][1]));
         }
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            f32x4 r0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(l0B + (224 + 16 * sub + e) * 16);
-                r0[e] = __builtin_fmaf(xy0.y, w[1], __builtin_fmaf(xy0.x, w[0], w[2]));
-            }
-            acc[1][sub] = r0;
-        }
+        for (int sub = 0; sub < 2; ++sub) acc[1][sub] = s0a[(size_t)(56 + 4 * sub) * p.P];
         tbl_load(0, modB, zeroB, 7, false);
 
-        part = 0.f;
+        part4[0] = part4[1] = part4[2] = part4[3] = 0.f;
         if constexpr (LFIX == 5) {
             MSIREN_H16_LAYER(Xh, Xl, Yh, Yl, 1, false);
             MSIREN_H16_LAYER(Yh, Yl, Xh, Xl, 2, false);
@@ -295,12 +286,10 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
         tbl_load(1, modB + (L - 1) * 1024, woutB, 7, true);
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            epi_half(acc[1][sub], p.cg, sub, 0, true, true);
-            epi_half(acc[1][sub], p.cg, sub, 1, true, true);
+            epi_half(acc[1][sub], p.cg, sub, 0, true, true, 3);
+            epi_half(acc[1][sub], p.cg, sub, 1, true, true, 3);
         }
-        float sv = part;
-        sv += __shfl_xor(sv, 16);
-        sv += __shfl_xor(sv, 32);
+        const float sv = (sum_over_q(part4[0]) + sum_over_q(part4[1])) + (sum_over_q(part4[2]) + sum_over_q(part4[3]));
         if (q == 0 && pv0) p.out[(size_t)b * p.P + pc0] = sin_rev(sv + p.bout);
         cur_pass = __builtin_amdgcn_readfirstlane(qslot[(pass + 1) & 1]);
     }

@@ -60,6 +60,23 @@ __device__ __forceinline__ void split_products_pk(float a0, float m0, float a1, 
     lo = __builtin_bit_cast(fp16x2, l);
 }
 
+// Sum of a lane's value over the four feature sub-groups q (lanes 16 apart), in every lane: rows 16 apart first, halves 32
+// apart second -- two lane swaps (gfx950) instead of two LDS-routed shuffles.
+__device__ __forceinline__ float sum_over_q(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a += b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+// THE ORDER OF THE last_layer SUM (every split-fp16 trunk produces the same bits for a coordinate, whichever instance and
+// batch it travelled in): per column, the 256 products v_f * (m_f * w_f) are accumulated in four chains of 64 features
+// (features 64 c .. 64 c + 63, c = 0..3: what one wave of the weight-stationary kernel owns), each chain a sequence of FMAs
+// over the lane's features in increasing order, summed over the four feature sub-groups q (sum_over_q), and the four
+// chains are added as (c0 + c1) + (c2 + c3); then + bias, then the sine.
+
 // LFIX: 0 = any depth (layer loop at run time); 5 = the YAML depth (num_layers = 5 in every shipped configuration)
 // with the four hidden layers as straight-line code.  The register-resident arrays X, Y then never meet at a loop
 // header, so register allocation does not depend on hipcc coalescing 256 phi copies (which it does for some
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
 
     h8 Xh[16], Xl[16], Yh[16], Yl[16];  // B fragments [2 * k-step + column group]
     f32x4 acc[2][4];                    // [tile parity][part], part = 2 * column group + sub-tile
-    float part[2] = {0.f, 0.f};         // last_layer dot product of the lane's two coordinates (its four features)
+    float part4[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // last_layer dot product: [column group][chain of 64 features]
 
     // epilogue of one 32-feature tile = 4 parts (column group g, 16-feature sub-tile sub), 4 elements each:
     // acc -> (revolutions) -> activation -> modulation -> fp16 split; parts (g, 0) and (g, 1) make up B fragment
@@ -143,11 +160,11 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
     fp16x2 eh[4][2], el[4][2];
     // modulation / last_layer weight of the two sub-tiles of the tile whose epilogue is in flight, and the bias
     // fragments (C operand) of the two sub-tiles of the NEXT tile
-    f32x4 tb_m[2], tb_w[2], bia[2];
+    f32x4 tb_m[2], bia[2];
     auto tbl_load = [&](int sub, const unsigned char* ml, const unsigned char* wo, int t, bool withw) {
         const int fo = (32 * t + 16 * sub) * 4;  // compile-time byte offset
         tb_m[sub] = *reinterpret_cast<const f32x4*>(ml + fo);
-        if (withw) tb_w[sub] = *reinterpret_cast<const f32x4*>(wo + fo);
+        if (withw) tb_m[sub] *= *reinterpret_cast<const f32x4*>(wo + fo);  // final layer: modulation x last_layer.weight
     };
     auto bias_load = [&](int sub, const unsigned char* bl, int t) {
         bia[sub] = *reinterpret_cast<const f32x4*>(bl + (32 * t + 16 * sub) * 4);
@@ -156,12 +173,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
     // half `hh` (elements 2hh, 2hh+1) of part pt: see epi_half of the 32x32 kernel
     // `fresh`: the accumulator was written by the MFMAs just before (the "pending" tile of the previous layer): plain
     // builtins, so that hipcc pads the MFMA -> VALU read hazard.  Elsewhere the accumulator is one tile (>= 12 MFMAs) old.
-    auto epi_half = [&](const f32x4& a, float cgl, int pt, int hh, bool lastl, bool fresh = false) {
+    // `ready`: the values are layer 0's last 32 features straight from the activation table (already activated).
+    auto epi_half = [&](const f32x4& a, float cgl, int pt, int hh, bool lastl, bool fresh = false, int chain = 0, bool ready = false) {
         const int sub = pt & 1, g = pt >> 1;
         float v[2];
         if (fresh) {
-            v[0] = activate<ACT>(a[2 * hh], cgl);
-            v[1] = activate<ACT>(a[2 * hh + 1], cgl);
+            v[0] = ready ? a[2 * hh] : activate<ACT>(a[2 * hh], cgl);
+            v[1] = ready ? a[2 * hh + 1] : activate<ACT>(a[2 * hh + 1], cgl);
         } else if constexpr (ACT == 0) {
             // The sine reads the accumulator (= its argument, in revolutions) directly.  Issued through asm so that it is
             // anchored to its MFMA group: instruction selection orders pure VALU code only by data dependence and would
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         }
         if (lastl) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) part[g] = __builtin_fmaf(v[e] * tb_m[sub][2 * hh + e], tb_w[sub][2 * hh + e], part[g]);
+            for (int e = 0; e < 2; ++e) part4[g][chain] = __builtin_fmaf(v[e], tb_m[sub][2 * hh + e], part4[g][chain]);
         } else {
             split_products_pk(v[0], tb_m[sub][2 * hh], v[1], tb_m[sub][2 * hh + 1], eh[pt][hh], el[pt][hh]);
         }
@@ -361,14 +379,14 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         } else if ((T) == 0) {                                                                       \
             if ((Q) == 0) tbl_load(1, mlp_, zeroB, 7, false);                                 \
             if ((Q) < 4) {                                                                    \
-                epi_half(acc[1][(Q) & 3], cgp_, (Q) & 3, 0, false, true);                     \
-                epi_half(acc[1][(Q) & 3], cgp_, (Q) & 3, 1, false, true);                     \
+                epi_half(acc[1][(Q) & 3], p.cg, (Q) & 3, 0, false, true, 0, l_ == 1);           \
+                epi_half(acc[1][(Q) & 3], p.cg, (Q) & 3, 1, false, true, 0, l_ == 1);           \
             }                                                                                 \
             if ((Q) == 4) epi_store2(0, INh[14], INl[14]);                                    \
             if ((Q) == 5) epi_store2(1, INh[15], INl[15]);                                    \
         } else {                                                                              \
             if ((Q) == 0) tbl_load(1, ml_, wo_, ((T) + 7) & 7, LASTF);                        \
-            epi_half(acc[((T) + 1) & 1][(Q) >> 1], p.cg, (Q) >> 1, (Q) & 1, LASTF);           \
+            epi_half(acc[((T) + 1) & 1][(Q) >> 1], p.cg, (Q) >> 1, (Q) & 1, LASTF, false, (((T) + 7) & 7) >> 1); \
             if ((Q) == 5 && !(LASTF)) epi_store2(0, OUTh[(2 * (T) + 14) & 15], OUTl[(2 * (T) + 14) & 15]); \
         }                                                                                     \
         /* bias fragments of the NEXT tile (its first MFMAs are a group or two away; bia is free after group 0) */ \
@@ -415,7 +433,6 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         const unsigned char* bnx_ = (LASTF) ? biasB : biasB + l_ * 1024;                      \
         const unsigned char* ml_ = modB + l_ * 1024;                                          \
         const unsigned char* mlp_ = modB + (l_ - 1) * 1024;                                   \
-        const float cgp_ = l_ > 1 ? p.cg : p.cg0;                                             \
         MSIREN_N16_TILE(INh, INl, OUTh, OUTl, 0, LASTF);                                        \
         MSIREN_N16_TILE(INh, INl, OUTh, OUTl, 1, LASTF);                                        \
         MSIREN_N16_TILE(INh, INl, OUTh, OUTl, 2, LASTF);                                        \
@@ -468,14 +485,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
             *reinterpret_cast<f32x4*>(modT + l * 256 + lane * 4) = m * mscaleT[l];  // exact: a power of two
         }
         if (tid == 0) qslot[(pass + 1) & 1] = nxt;  // read after >= 32 workgroup barriers
-        const float2 xy0 = reinterpret_cast<const float2*>(p.grid)[pc0];
-        const float2 xy1 = reinterpret_cast<const float2*>(p.grid)[pc1];
 
         // ---- layer 0 (K = 2) from the per-weight-set table act0(W0 x_p + b0), directly in B-operand order:
         //      element j of fragment [2 s + g] is feature 32 s + 16 (j >> 2) + 4 q + (j & 3) at the lane's
         //      coordinate of column group g.  K-steps 0..6 are finished here; the last 32 features ("tile 7")
-        //      are left as sine ARGUMENTS in acc[1], where the first hidden layer's pending-epilogue slot turns
-        //      them into X[14], X[15].
+        //      wait in acc[1] as they come from the table, where the first hidden layer's pending-epilogue slot
+        //      turns them into X[14], X[15] (modulation and split only: `ready`).  Every split-fp16 trunk takes all
+        //      256 layer-0 activations from this table, so that they agree bit for bit.
         const f32x4* s0a = reinterpret_cast<const f32x4*>(p.s0t) + (size_t)q * p.P + pc0;
         const f32x4* s0b = reinterpret_cast<const f32x4*>(p.s0t) + (size_t)q * p.P + pc1;
         f32x4 raw[14][2];  // [2 s + g][sub]: all 28 loads in flight at once
@@ -506,20 +522,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            f32x4 r0, r1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(l0B + (224 + 16 * sub + e) * 16);
-                r0[e] = __builtin_fmaf(xy0.y, w[1], __builtin_fmaf(xy0.x, w[0], w[2]));
-                r1[e] = __builtin_fmaf(xy1.y, w[1], __builtin_fmaf(xy1.x, w[0], w[2]));
-            }
-            acc[1][0 + sub] = r0;
-            acc[1][2 + sub] = r1;
+            acc[1][0 + sub] = s0a[(size_t)(56 + 4 * sub) * p.P];
+            acc[1][2 + sub] = s0b[(size_t)(56 + 4 * sub) * p.P];
         }
         tbl_load(0, modB, zeroB, 7, false);  // sub-tile 0 of the layer-0 "pending" tile
 
-        part[0] = 0.f;
-        part[1] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) part4[0][c] = part4[1][c] = 0.f;
         stamp(1);
         // Hidden layers alternate X->Y and Y->X; the final hidden layer has its own instances (see the 32x32 kernel).
         if constexpr (LFIX == 5) {
@@ -548,15 +557,12 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         tbl_load(1, modB + (L - 1) * 1024, woutB, 7, true);
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-            epi_half(acc[1][pt], p.cg, pt, 0, true, true);
-            epi_half(acc[1][pt], p.cg, pt, 1, true, true);
+            epi_half(acc[1][pt], p.cg, pt, 0, true, true, 3);
+            epi_half(acc[1][pt], p.cg, pt, 1, true, true, 3);
         }
-        // sum over the four feature sub-groups (q); lanes q == 0 / q == 1 store column group 0 / 1
-        float s0v = part[0], s1v = part[1];
-        s0v += __shfl_xor(s0v, 16);
-        s1v += __shfl_xor(s1v, 16);
-        s0v += __shfl_xor(s0v, 32);
-        s1v += __shfl_xor(s1v, 32);
+        // the canonical last_layer sum (see above); lanes q == 0 / q == 1 store column group 0 / 1
+        const float s0v = (sum_over_q(part4[0][0]) + sum_over_q(part4[0][1])) + (sum_over_q(part4[0][2]) + sum_over_q(part4[0][3]));
+        const float s1v = (sum_over_q(part4[1][0]) + sum_over_q(part4[1][1])) + (sum_over_q(part4[1][2]) + sum_over_q(part4[1][3]));
         {
             const float sv = q == 0 ? s0v : s1v;
             const int pc = q == 0 ? pc0 : pc1;

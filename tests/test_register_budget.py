@@ -67,3 +67,45 @@ def test_trunk_and_its_neighbours_fit_on_one_cu(tmp_path):
     for k, u in beside.items():
         assert alloc(u) <= free, (k, u, free)
         assert u["LDS"] <= 34 * 1024, (k, u)  # what a ring of 3 leaves free
+
+
+WS_TU = r"""
+#include <hip/hip_runtime.h>
+#include "siren_trunk_f16x3w.hip.h"
+template __global__ void msiren::siren_trunk_f16x3w_kernel<0, 4, 0>(msiren::TrunkWsParams);
+template __global__ void msiren::siren_trunk_f16x3w_kernel<1, 4, 0>(msiren::TrunkWsParams);
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_weight_stationary_trunk_owns_its_register_files(tmp_path):
+    """siren_trunk_f16x3w.hip.h manages a[0:255] (weight fragments) and v[192:255] (accumulators) BY NAME in asm
+    statements; the compiler is kept out of them (amdgpu_num_vgpr(192) + placeholder values).  Should a compiler or source
+    change let it back in -- a value parked in an AGPR over the fragments, a spill, an allocation beyond v191 -- results
+    would be silently wrong or the kernel would fault: checked in the ISA, at build time."""
+    src = tmp_path / "ws.hip"
+    src.write_text(WS_TU)
+    asm = tmp_path / "ws.s"
+    cmd = [HIPCC, "-O3", "-std=c++17", "-S", "--cuda-device-only", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "mri_inr_amd", "csrc"),
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-fno-slp-vectorize", str(src), "-o", str(asm)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    text = asm.read_text()
+    kernels = re.split(r"\n(?=_ZN6msiren25siren_trunk_f16x3w_kernel)", text)[1:]
+    assert len(kernels) == 2
+    for k in kernels:
+        body = k.split(".amdhsa_kernel")[0]
+        assert "v_accvgpr" not in body and "scratch_" not in body
+        assert body.count("v_mfma_f32_16x16x32_f16") == 12 * 192          # twelve slot bodies (variant x parity x flavour)
+        for line in body.splitlines():
+            code = line.split(";")[0]
+            if re.search(r"\ba\[", code):                               # an AGPR operand: only where the kernel put it
+                assert code.split()[0] in ("v_mfma_f32_16x16x32_f16", "global_load_dwordx4"), line
+            hi = [int(x, 0) for x in re.findall(r"\bv\[(0x[0-9a-f]+|\d+):", code)] + [int(x) for x in re.findall(r"\bv(\d+)\b", code)]
+            if hi and max(hi) >= 192:                                     # an accumulator register: MFMA, or the sine / move that reads it
+                assert code.split()[0] in ("v_mfma_f32_16x16x32_f16", "v_sin_f32", "v_mov_b32"), line
+    for m in re.finditer(r"\.amdhsa_next_free_vgpr (\d+)", text):
+        assert int(m.group(1)) == 512
+    for m in re.finditer(r"\.amdhsa_accum_offset (\d+)", text):
+        assert int(m.group(1)) == 256
+    assert len(re.findall(r"\.amdhsa_next_free_vgpr", text)) == 2
