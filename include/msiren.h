@@ -43,7 +43,9 @@ enum {
     MSIREN_E_STATE = -2,    /* call order: weights missing or not committed (RuntimeError)    */
     MSIREN_E_SHAPE = -3,    /* tensor size does not match the configuration (load_state_dict) */
     MSIREN_E_HIP = -4,      /* HIP runtime error (message carries hipGetErrorString)          */
-    MSIREN_E_NOMEM = -5
+    MSIREN_E_NOMEM = -5,
+    MSIREN_E_RANGE = -6     /* an operand left the domain of the handle's arithmetic (split-fp16 trunk: a modulation
+                               beyond what fp16 carries, or a NaN / inf); reported by the next synchronising call */
 };
 
 enum { MSIREN_ACT_SINE = 0, MSIREN_ACT_MORLET = 1 };
@@ -53,10 +55,13 @@ enum {
     MSIREN_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32, the parity path (configs 1-4) */
     MSIREN_PREC_BF16 = 1, /* bf16 operands, fp32 accumulate: register-resident single-product trunk,
                              dim_hidden = 512, num_layers <= 12 (BASELINE config 5; own tolerance)  */
-    MSIREN_PREC_F16X3 = 2, /* split-fp16: 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate;
+    MSIREN_PREC_F16X3 = 2, /* split-fp16: 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate;
                              fp32-equivalent accuracy (22-bit operands); H = 256, 2 <= L <= 11 (the
-                             per-layer tables must fit the 160 KB LDS beside the weight ring).
-                             Other shapes silently use MSIREN_PREC_F32.                          */
+                             per-layer tables must fit the 160 KB LDS beside the weight ring; depths
+                             3..5 run the weight-stationary kernel on single-stream handles).
+                             Other shapes silently use MSIREN_PREC_F32.  A modulation, activation or
+                             weight outside what fp16 operands can carry makes the forward call fail
+                             with MSIREN_E_RANGE instead of returning inf / NaN (see msiren_sync). */
     MSIREN_PREC_F16 = 3   /* as BF16 with fp16 operands (11-bit significand)                        */
 };
 
@@ -237,14 +242,26 @@ MSIREN_API int msiren_profile_read(msiren_handle h, int64_t* launches, double* t
 MSIREN_API int msiren_device_info(msiren_handle h, char* name256, int32_t* compute_units, int32_t* clock_mhz,
                        uint64_t* hbm_bytes);
 MSIREN_API int msiren_device_count(int32_t* count);
+/* Domain guard of the split-fp16 trunk (MSIREN_PREC_F16X3).  Its fp16 operands carry activation x modulation x the next
+ * layer's power-of-two weight scale; the weights are scaled into range at commit, a modulation cannot be known before the
+ * call.  Every trunk launch checks the scaled modulations it stages: if one exceeds 65504 (or is not finite) a flag is raised
+ * and
+ *   - a host-pointer call (msiren_forward_mods / _latent / _tiles, msiren_reconstruct_slices) runs itself again on the
+ *     exact-fp32 trunk and returns that result;
+ *   - after *_dev calls the next msiren_sync (or any other synchronising call) returns MSIREN_E_RANGE: the outputs since
+ *     the previous sync are not valid.
+ * The reference's fp32 arithmetic (modulated_siren.py:215-233) has no such bound; this is what keeps "auto" precision from
+ * returning inf / NaN where it would not.  msiren_range_events: launches that raised the flag since msiren_create. */
+MSIREN_API int msiren_range_events(msiren_handle h, int64_t* count);
 /* Algorithmic FLOPs per coordinate for the handle's configuration: 2*2*H + (L-1)*2*H*H + 2*H. */
 MSIREN_API int msiren_flops_per_coord(msiren_handle h, double* flops);
 MSIREN_API int msiren_abi_version(void);
 /* Diagnostic (H=256, sine only): runs a stamped build of the trunk kernel once and returns, per
  * workgroup, 32 uint64: [0] HW_ID, [1] LDS_ALLOC, [2] XCC_ID, [3] s_memrealtime at start,
  * [4..] s_memtime at each phase boundary.  Never used by the forward entry points. */
-/* Same for the f16x3 trunk: per workgroup and pass (first 8), 8 uint64: s_memtime at pass start, after
- * layer 0, after hidden layers 1..4, at pass end, and s_memrealtime at pass end.  (H=256, L=5, sine.) */
+/* Same for the register-resident f16x3 trunk: per workgroup and pass (first 4), 48 uint64: [0] s_memtime at pass
+ * start, [1] after layer 0, [2] after the hidden layers, [6] at pass end, [7] s_memrealtime at pass end, [8..39]
+ * s_memtime at the end of each of the 32 hidden-layer tiles.  (H=256, L=5, sine.) */
 MSIREN_API int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev,
                                      uint64_t* stamps_host);
 /* Same for the weight-stationary f16x3 trunk: per workgroup and slot (first 96), 4 uint64: s_memtime at the top of the

@@ -20,7 +20,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msiren.h")
 ABI_VERSION = 1
 ACT_SINE, ACT_MORLET = 0, 1
 PREC_F32, PREC_BF16, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
-E_INVALID, E_STATE, E_SHAPE, E_HIP, E_NOMEM = -1, -2, -3, -4, -5
+E_INVALID, E_STATE, E_SHAPE, E_HIP, E_NOMEM, E_RANGE = -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
 
 
@@ -89,6 +89,7 @@ PROTOTYPES = {
     "msiren_profile_read": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
     "msiren_device_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_uint64)]),
     "msiren_flops_per_coord": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "msiren_range_events": (C.c_int, [_vp, C.POINTER(_i64)]),
     "msiren_comm_unique_id": (C.c_int, [_vp, C.c_size_t]),
     "msiren_comm_init_rank": (C.c_int, [_vp, _vp, C.c_size_t, _i32, _i32]),
     "msiren_comm_init_all": (C.c_int, [C.POINTER(_vp), _i32]),
@@ -109,6 +110,10 @@ _lock = threading.Lock()
 
 class MsirenError(RuntimeError):
     """HIP/runtime failure inside libmsiren (E_HIP, E_STATE, E_NOMEM)."""
+
+
+class MsirenRangeError(MsirenError, FloatingPointError):
+    """E_RANGE: an operand left the domain of the split-fp16 trunk (see include/msiren.h, msiren_range_events)."""
 
 
 def build(verbose: bool = False) -> str:
@@ -174,6 +179,8 @@ def check(rc: int):
     msg = last_error()
     if rc in (E_INVALID,):
         raise ValueError(msg)
+    if rc == E_RANGE:
+        raise MsirenRangeError(msg)
     if rc == E_SHAPE:
         # torch's load_state_dict raises RuntimeError("... size mismatch ...")
         raise RuntimeError(msg)

@@ -89,6 +89,12 @@ struct msiren_ctx {
     int lds_attr_f16n[2][4] = {};
     int lds_attr_f16h[2][2] = {};  // half-unit instances (num_layers = 5 only)
     int lds_attr_f16w[2] = {};     // weight-stationary instances ([activation])
+    int lds_attr_f32[4] = {}, lds_attr_x1 = 0;  // exact-fp32 trunk ([activation][residual]) / single-product 16-bit trunk
+    // f16x3 domain guard: a word in host memory the trunk kernels set when a scaled modulation does not fit fp16
+    volatile int* status_host = nullptr;
+    int* status_dev = nullptr;
+    bool f16_off = false;          // the call in flight is the exact-fp32 re-run of a host-pointer call
+    int64_t range_events = 0;      // launches that raised the flag (re-run or reported) since create
     float* d_dump = nullptr;       // 256 floats: where lanes of the weight-stationary trunk that have nothing to store write
     int f16_ws = 1;                // the weight-stationary trunk runs single-stream launches (MSIREN_F16_WS=0: never; read at create)
     float *d_bias16 = nullptr, *d_wout16 = nullptr, *d_s0t = nullptr;
@@ -290,7 +296,10 @@ int pack_trunk_f16x3(msiren_ctx* h) {
     if (h->cfg.precision != MSIREN_PREC_F16X3 || H != 256 || L < 2 || msiren::F16Lds<3>::total(L) > 160 * 1024) return 0;
     const double two_pi = 6.283185307179586476925286766559;
     const double c = (double)h->cfg.w0 / two_pi;
-    std::vector<uint16_t> wp((size_t)(L - 1) * 8 * 16 * 2 * 64 * 8), wpn(wp.size());
+#ifdef MSIREN_WITH_TILE32
+    std::vector<uint16_t> wp((size_t)(L - 1) * 8 * 16 * 2 * 64 * 8);  // stream of the 32x32x16 kernel (A/B builds only)
+#endif
+    std::vector<uint16_t> wpn((size_t)(L - 1) * 8 * 16 * 2 * 64 * 8);
     std::vector<float> bias((size_t)(L - 1) * 256, 0.f), wout(256, 0.f);
     for (int l = 1; l < L; ++l) {
         const std::vector<float>& w = *get(h, "net.layers." + std::to_string(l) + ".weight");
@@ -301,6 +310,7 @@ int pack_trunk_f16x3(msiren_ctx* h) {
         e = std::max(-14, std::min(e, 30));
         const double sc = std::ldexp(c, e);
         h->winv16[l - 1] = (float)std::ldexp(1.0, -e);
+#ifdef MSIREN_WITH_TILE32
         for (int t = 0; t < 8; ++t)
             for (int s = 0; s < 16; ++s)
                 for (int lane = 0; lane < 64; ++lane)
@@ -314,6 +324,7 @@ int pack_trunk_f16x3(msiren_ctx* h) {
                         wp[base + (size_t)lane * 8 + j] = hi;
                         wp[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
                     }
+#endif
         // 16x16x32 kernel (siren_trunk_f16x3n.hip.h): chunk (l, t) = [8 k-steps][2 sub-tiles][hi|lo][64 lanes][8 x f16];
         // lane (r = lane & 15, q = lane >> 4), element j of k-step s of sub-tile u: output feature 32 t + 16 u + r,
         // input feature 32 s + 16 (j >> 2) + 4 q + (j & 3).  Scale 2^a with rms|W'| ~ 0.1 (a is undone on the
@@ -349,10 +360,12 @@ int pack_trunk_f16x3(msiren_ctx* h) {
     h->mscale16[L - 1] = 1.0f;  // the last hidden layer's output meets last_layer unscaled
     const auto* Wo = get(h, "net.last_layer.weight");
     for (int f = 0; f < H; ++f) wout[f] = (float)((double)(*Wo)[f] * c);
+#ifdef MSIREN_WITH_TILE32
     if (h->d_wp16) HIPCHK(hipFree(h->d_wp16));
     h->d_wp16 = nullptr;
     HIPCHK(hipMalloc(&h->d_wp16, wp.size() * 2));
     HIPCHK(hipMemcpy(h->d_wp16, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+#endif
     if (h->d_wp16n) HIPCHK(hipFree(h->d_wp16n));
     h->d_wp16n = nullptr;
     HIPCHK(hipMalloc(&h->d_wp16n, wpn.size() * 2));
@@ -577,8 +590,11 @@ int launch_trunk_hp(msiren_ctx* h, const msiren::TrunkParams& p, int grid) {
 #define MSIREN_LAUNCH(A, R)                                                                        \
     do {                                                                                           \
         auto k = msiren::siren_trunk_f32_kernel<HP, A, R>;                                         \
-        if (lds > 64 * 1024)                                                                       \
+        int& done = h->lds_attr_f32[(A) * 2 + (R)]; /* one instance per handle: HP, activation and residual are the handle's */ \
+        if (lds > 64 * 1024 && done < (int)lds) {                                                  \
             HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            done = (int)lds;                                                                       \
+        }                                                                                          \
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);                           \
     } while (0)
     if (act == MSIREN_ACT_MORLET) {
@@ -728,6 +744,7 @@ int launch_trunk_f16x3w(msiren_ctx* h, const float* mods_dev, int64_t B, float* 
     p.P = h->P;
     p.L = h->L;
     p.plan = h->plan;
+    p.status = h->status_dev;
     const int upp = (h->P + 31) / 32;
     const int64_t units = B * upp;
     if (units > 0x3fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
@@ -790,6 +807,7 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     p.P = h->P;
     p.L = h->L;
     p.plan = h->plan;
+    p.status = h->status_dev;
     const int upp = (h->P + 31) / 32;
     const int64_t units = B * upp;
     if (units > 0x3fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
@@ -867,7 +885,10 @@ int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int gr
 #define MSIREN_X1_LAUNCH(BF, A, RS)                                                                  \
     do {                                                                                             \
         auto k = msiren::siren_trunk_x1_kernel<BF, A, RS, 3>;                                        \
-        HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        if (h->lds_attr_x1 < lds) { /* one instance per handle (precision, activation, residual are the handle's) */ \
+            HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            h->lds_attr_x1 = lds;                                                                    \
+        }                                                                                            \
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);                       \
     } while (0)
     if (bf) {
@@ -883,7 +904,7 @@ int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int gr
 }
 
 bool use_f16x3(msiren_ctx* h) {
-    return h->cfg.precision == MSIREN_PREC_F16X3 && h->f16x3_ready && !h->cfg.residual &&
+    return !h->f16_off && h->cfg.precision == MSIREN_PREC_F16X3 && h->f16x3_ready && !h->cfg.residual &&
            msiren::F16Lds<3>::total(h->L) <= 160 * 1024;
 }
 
@@ -1059,10 +1080,37 @@ int forward_tiles_dev(msiren_ctx* h, const float* tiles_dev, int64_t B, float* o
     return forward_latent_dev(h, (const float*)h->sc[h->cur].latent.p, B, out_dev, nullptr);
 }
 
+// the f16x3 domain guard's flag: set by a trunk launch that met a scaled modulation beyond fp16 (or a NaN / inf)
+bool take_range_flag(msiren_ctx* h) {
+    if (!h->status_host || !*h->status_host) return false;
+    *h->status_host = 0;
+    h->range_events++;
+    return true;
+}
+
 int sync_all(msiren_ctx* h) {
     for (auto& c : h->sc)
         if (c.s) HIPCHK(hipStreamSynchronize(c.s));
+    if (!h->f16_off && take_range_flag(h))
+        return fail(MSIREN_E_RANGE, "a modulation (times the layer's power-of-two weight scale) exceeds what the split-fp16 trunk's fp16 "
+                                    "operands can carry (65504), or is not finite: the outputs of the calls since the last sync are not valid. "
+                                    "Use precision=\"fp32\" (MSIREN_PREC_F32) for this model, or the host-pointer entry points, which re-run such a "
+                                    "call on the exact-fp32 trunk by themselves");
     return 0;
+}
+
+// Host-pointer (synchronous) calls: a call that raised the flag is run again on the exact-fp32 trunk -- still the HIP path,
+// 3x slower, right -- so that precision "auto" never returns inf / NaN where the reference's fp32 would not.
+template <typename F>
+int with_range_fallback(msiren_ctx* h, F&& run) {
+    int rc = run();
+    if (rc == MSIREN_E_RANGE || (rc == 0 && take_range_flag(h))) {
+        h->f16_off = true;
+        rc = run();
+        h->f16_off = false;
+        (void)take_range_flag(h);
+    }
+    return rc;
 }
 
 // asynchronous forward entry points rotate over the configured streams
@@ -1227,6 +1275,11 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     hipError_t e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->sc[0].s, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->sc[1].s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->status_host, 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *h->status_host = 0;
+        e = hipHostGetDevicePointer((void**)&h->status_dev, (void*)h->status_host, 0);
+    }
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -1243,6 +1296,7 @@ int msiren_destroy(msiren_handle h) {
     for (auto& c : h->sc)
         if (c.s) (void)hipStreamSynchronize(c.s);
     if (h->comm) (void)msiren_comm_destroy(h);
+    if (h->status_host) (void)hipHostFree((void*)h->status_host);
     if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
     if (h->d_wp16) (void)hipFree(h->d_wp16);
     if (h->d_wp16n) (void)hipFree(h->d_wp16n);
@@ -1316,7 +1370,7 @@ int msiren_forward_mods_dev(msiren_handle h, const float* mods_dev, int64_t B, f
     return launch_trunk(h, mods_dev, B, out_dev);
 }
 
-int msiren_forward_mods(msiren_handle h, const float* mods_host, int64_t B, float* out_host) {
+static int msiren_forward_mods_impl(msiren_handle h, const float* mods_host, int64_t B, float* out_host) {
     int rc = check(h);
     if (rc) return rc;
     if (B < 0 || (B > 0 && (!mods_host || !out_host))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
@@ -1330,6 +1384,11 @@ int msiren_forward_mods(msiren_handle h, const float* mods_host, int64_t B, floa
     return 0;
 }
 
+int msiren_forward_mods(msiren_handle h, const float* mods_host, int64_t B, float* out_host) {
+    if (!h) return fail(MSIREN_E_INVALID, "null handle");
+    return with_range_fallback(h, [&] { return msiren_forward_mods_impl(h, mods_host, B, out_host); });
+}
+
 int msiren_forward_latent_dev(msiren_handle h, const float* z_dev, int64_t B, float* out_dev, float* mods_out_dev) {
     int rc = check(h);
     if (rc) return rc;
@@ -1338,7 +1397,7 @@ int msiren_forward_latent_dev(msiren_handle h, const float* z_dev, int64_t B, fl
     return forward_latent_dev(h, z_dev, B, out_dev, mods_out_dev);
 }
 
-int msiren_forward_latent(msiren_handle h, const float* z_host, int64_t B, float* out_host, float* mods_out_host) {
+static int msiren_forward_latent_impl(msiren_handle h, const float* z_host, int64_t B, float* out_host, float* mods_out_host) {
     int rc = check(h);
     if (rc) return rc;
     if (B < 0 || (B > 0 && (!z_host || !out_host))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
@@ -1354,6 +1413,11 @@ int msiren_forward_latent(msiren_handle h, const float* z_host, int64_t B, float
     return 0;
 }
 
+int msiren_forward_latent(msiren_handle h, const float* z_host, int64_t B, float* out_host, float* mods_out_host) {
+    if (!h) return fail(MSIREN_E_INVALID, "null handle");
+    return with_range_fallback(h, [&] { return msiren_forward_latent_impl(h, z_host, B, out_host, mods_out_host); });
+}
+
 int msiren_forward_tiles_dev(msiren_handle h, const float* tiles_dev, int64_t B, float* out_dev) {
     int rc = check(h);
     if (rc) return rc;
@@ -1363,7 +1427,7 @@ int msiren_forward_tiles_dev(msiren_handle h, const float* tiles_dev, int64_t B,
     return forward_tiles_dev(h, tiles_dev, B, out_dev);
 }
 
-int msiren_forward_tiles(msiren_handle h, const float* tiles_host, int64_t B, float* out_host) {
+static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, int64_t B, float* out_host) {
     int rc = check(h);
     if (rc) return rc;
     if (B < 0 || (B > 0 && (!tiles_host || !out_host))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
@@ -1402,6 +1466,11 @@ int msiren_forward_tiles(msiren_handle h, const float* tiles_host, int64_t B, fl
     h->cur = cur0;
     const int rs = sync_all(h);
     return rc ? rc : rs;
+}
+
+int msiren_forward_tiles(msiren_handle h, const float* tiles_host, int64_t B, float* out_host) {
+    if (!h) return fail(MSIREN_E_INVALID, "null handle");
+    return with_range_fallback(h, [&] { return msiren_forward_tiles_impl(h, tiles_host, B, out_host); });
 }
 
 int msiren_recon_shape(msiren_handle h, int32_t height, int32_t width, int32_t* nv, int32_t* nh) {
@@ -1521,7 +1590,7 @@ int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int6
     return reconstruct_on_current_stream(h, images_dev, n, height, width, recon_dev);
 }
 
-int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t n, int32_t height, int32_t width, float* recon_host) {
+static int msiren_reconstruct_slices_impl(msiren_handle h, const float* images_host, int64_t n, int32_t height, int32_t width, float* recon_host) {
     int rc = check(h);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!images_host || !recon_host))) return fail(MSIREN_E_INVALID, "bad arguments");
@@ -1536,6 +1605,11 @@ int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t
     HIPCHK(hipMemcpyAsync(recon_host, h->ws_img.p, nr, hipMemcpyDeviceToHost, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
     return 0;
+}
+
+int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t n, int32_t height, int32_t width, float* recon_host) {
+    if (!h) return fail(MSIREN_E_INVALID, "null handle");
+    return with_range_fallback(h, [&] { return msiren_reconstruct_slices_impl(h, images_host, n, height, width, recon_host); });
 }
 
 int msiren_set_streams(msiren_handle h, int32_t n) {
@@ -1934,6 +2008,12 @@ int msiren_comm_destroy(msiren_handle h) {
     h->comm = nullptr;
     h->comm_n = 1;
     h->comm_rank = 0;
+    return 0;
+}
+
+int msiren_range_events(msiren_handle h, int64_t* count) {
+    if (!h || !count) return fail(MSIREN_E_INVALID, "null argument");
+    *count = h->range_events;
     return 0;
 }
 

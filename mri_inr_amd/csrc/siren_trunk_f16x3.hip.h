@@ -52,6 +52,7 @@ struct TrunkF16Params {
     int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
     unsigned pass_base;        // value of *pass_counter when this launch starts (arithmetic is modulo 2^32)
     unsigned long long* stamps; // diagnostic instantiation only: [grid][8 passes][8] s_memtime + realtime
+    int* status;              // domain guard: set to 1 when a scaled modulation does not fit fp16 (host-mapped word; may be null)
 };
 
 constexpr int F16_CHUNK_BYTES = 32768;
@@ -68,6 +69,15 @@ struct F16Lds {  // byte offsets into dynamic LDS
     static __host__ __device__ constexpr int winv(int L) { return queue(L) + 16; }  // per-layer inverse weight scales
     static __host__ __device__ constexpr int total(int L) { return winv(L) + 64; }
 };
+
+// Domain of the split-fp16 arithmetic on the activation side: x' = a * (m * 2^-a_next) is rounded to fp16 (hi) with |a| <= 1,
+// so a scaled modulation beyond fp16's largest finite value (or a NaN / inf) would give inf / NaN silently.  Checked where the
+// modulation rows are staged (a handful of compares per unit); the flag is a word in host memory the library reads at its
+// next synchronisation (MSIREN_E_RANGE, or the exact-fp32 re-run of a host-pointer call).
+__device__ __forceinline__ bool f16_out_of_range(const f32x4 m) {
+    return !(__builtin_fabsf(m[0]) <= 65504.f) || !(__builtin_fabsf(m[1]) <= 65504.f) || !(__builtin_fabsf(m[2]) <= 65504.f) ||
+           !(__builtin_fabsf(m[3]) <= 65504.f);
+}
 
 __device__ __forceinline__ h8 pack_h8(fp16x2 a, fp16x2 b, fp16x2 c, fp16x2 d) {
     u32x4 u;

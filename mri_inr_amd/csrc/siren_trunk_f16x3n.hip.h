@@ -480,10 +480,14 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
         int nxt = 0;
         if (tid == 0) nxt = (int)((unsigned)atomicAdd(p.pass_counter, 1) - p.pass_base) + (int)gridDim.x;
         // this wave's modulation table: (L, 256) floats of patch b
+        bool bad_mod = false;
         for (int l = 0; l < L; ++l) {
             const f32x4 m = *reinterpret_cast<const f32x4*>(p.mods + ((size_t)l * p.B + b) * 256 + lane * 4);
-            *reinterpret_cast<f32x4*>(modT + l * 256 + lane * 4) = m * mscaleT[l];  // exact: a power of two
+            const f32x4 ms = m * mscaleT[l];  // exact: a power of two
+            bad_mod |= f16_out_of_range(ms);
+            *reinterpret_cast<f32x4*>(modT + l * 256 + lane * 4) = ms;
         }
+        if (bad_mod && p.status) *p.status = 1;
         if (tid == 0) qslot[(pass + 1) & 1] = nxt;  // read after >= 32 workgroup barriers
 
         // ---- layer 0 (K = 2) from the per-weight-set table act0(W0 x_p + b0), directly in B-operand order:

@@ -94,6 +94,7 @@ struct TrunkWsParams {
     int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
     unsigned pass_base;
     unsigned long long* stamps;
+    int* status;              // domain guard (f16_out_of_range): host-mapped word, may be null
 };
 
 template <int NB>
@@ -268,8 +269,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         ra = ra >= NR ? ra - NR : ra;
         rb = rb >= NR ? rb - NR : rb;
         rb = rb >= NR ? rb - NR : rb;
-        if (q < L) *reinterpret_cast<f32x4*>(modsW + (slot_unit * NR + ra) * 1024 + n16 * 16) = m[0] * msc0;
-        if (4 + q < L) *reinterpret_cast<f32x4*>(modsW + (slot_unit * NR + rb) * 1024 + n16 * 16) = m[1] * msc1;
+        const f32x4 ma = m[0] * msc0, mb = m[1] * msc1;
+        if ((f16_out_of_range(ma) || f16_out_of_range(mb)) && p.status) *p.status = 1;  // (clamped rows repeat a checked one)
+        if (q < L) *reinterpret_cast<f32x4*>(modsW + (slot_unit * NR + ra) * 1024 + n16 * 16) = ma;
+        if (4 + q < L) *reinterpret_cast<f32x4*>(modsW + (slot_unit * NR + rb) * 1024 + n16 * 16) = mb;
     };
 
     // layer 0 of one unit, this wave's 64 features: table -> x modulation -> fp16 split -> the unit image (k-steps 2 wave, 2 wave + 1)

@@ -7,8 +7,8 @@ Mirrors test_mod_siren.py of the reference (:78-262): build ``ModulatedSiren`` f
 load ``config.testing.model_path``, reconstruct ``config.data.metric_samples`` slices and write
 ``metrics_error.csv`` + ``metrics_summary.txt`` (same formats, :38-75, :236-247) under
 ``{output_dir}/{output_name}/test``.  Differences, all forced by the container:
-  * ``image_to_patches`` / ``metrics_error`` are the mirrors in ``mri_inr_amd/harness.py`` (same names, same
-    arguments, :205-232): tiling, black filter, model, weighted fold and the fold of the fully-sampled tiles
+  * ``image_to_patches`` / ``metrics_error`` are the mirrors in ``mri_inr_amd/harness.py`` (same names, same positional
+    arguments, :205-232; ``harness.bind(model)`` names the handle the free tiling functions run on): tiling, black filter, model, weighted fold and the fold of the fully-sampled tiles
     the reconstruction is scored against (error.py:229-254) run in libmsiren's kernels;
   * ``data.dataset: synthetic`` / ``testing.model_path: synthetic`` select seeded synthetic slices and
     weights (no fastMRI data or checkpoints here); a directory of ``*.npy`` slice pairs
@@ -29,8 +29,17 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from mri_inr_amd import ModulatedSiren, load_configuration, model_kwargs, synthetic  # noqa: E402
 from mri_inr_amd.configuration import parse_args  # noqa: E402
+from mri_inr_amd import harness  # noqa: E402
 from mri_inr_amd.harness import image_to_patches, metrics_error  # noqa: E402
 from mri_inr_amd.weights import load_checkpoint  # noqa: E402
+
+
+def save_args_to_file(args, output_dir):
+    """``config.txt``: one ``name: value`` line per top-level entry of the configuration (reference :18-33)."""
+    os.makedirs(output_dir, exist_ok=True)
+    with open(os.path.join(output_dir, "config.txt"), "w") as f:
+        for arg, value in vars(args).items():
+            f.write(f"{arg}: {value}\n")
 
 
 def save_metrics_summary(psnr_values, ssim_values, nrmse_values, output_dir):
@@ -62,6 +71,7 @@ def test_mod_siren(config):
     print("Testing the modulated SIREN...")
     output_dir = f"{config.testing.output_dir}/{config.testing.output_name}/test"
     os.makedirs(output_dir, exist_ok=True)
+    save_args_to_file(config, output_dir)
     model = ModulatedSiren(**model_kwargs(config, device="cuda", modulate=True))
     if config.testing.model_path == "synthetic":
         sd = synthetic.make_state_dict(seed=7, dim_hidden=config.model.dim_hidden, num_layers=config.model.num_layers,
@@ -73,6 +83,7 @@ def test_mod_siren(config):
     model.load_state_dict(sd)
     model.to("cuda")
     model.eval()
+    harness.bind(model)  # the tiling functions below run on this model's device / stream
 
     names, psnrs, ssims, nrmses = [], [], [], []
     t_gpu = 0.0
@@ -82,8 +93,10 @@ def test_mod_siren(config):
         print(f"Processing metric sample {i + 1}...")
         t0 = time.perf_counter()
         # unsqueeze image to add batch dimension (reference :206-207), tile both images, score
-        fully_sampled_patch, _ = image_to_patches(model, full[None], O, I)
-        undersampled_patch, undersampled_information = image_to_patches(model, under[None], O, I)
+        # (device-resident: the slices go up once, the tiles never come back to the host)
+        fully_sampled_patch, _ = image_to_patches(model.device_array((1,) + full.shape).copy_from(full[None]), O, I)
+        undersampled_patch, undersampled_information = image_to_patches(
+            model.device_array((1,) + under.shape).copy_from(under[None]), O, I)
         psnr, ssim, nrmse = metrics_error(model, fully_sampled_patch, undersampled_patch, undersampled_information,
                                           "cuda", O, I, S)
         t_gpu += time.perf_counter() - t0

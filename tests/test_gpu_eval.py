@@ -74,6 +74,9 @@ def test_eval_driver_artefacts_and_scores(tmp_path):
         got[name] = (float(psnr), float(ssim), float(nrmse))
     assert sorted(got) == sorted(sizes)
 
+    cfg_txt = (out / "config.txt").read_text().splitlines()   # save_args_to_file (reference test_mod_siren.py:18-33): "name: value"
+    assert any(l.startswith("model: ") for l in cfg_txt) and any(l.startswith("testing: ") for l in cfg_txt), cfg_txt
+
     summary = (out / "metrics_summary.txt").read_text()
     m = re.fullmatch(r"(?:(?:PSNR|SSIM|NRMSE):\n(?:  (?:mean|std|min|max): \S+\n){4}\n){3}", summary)
     assert m, summary
@@ -108,13 +111,14 @@ def test_harness_mirror_matches_oracle_tiling():
     m.load_state_dict(sd)
     m.to("cuda").eval()
     imgs = np.stack([syn.make_slice(k, 120, 88, brain_mask=(k == 0)) for k in range(2)])
-    tiles, info = harness.image_to_patches(m, imgs, 32, 16)
+    harness.bind(m)
+    tiles, info = harness.image_to_patches(imgs, 32, 16)                       # the reference's positional signature (tiling.py:10)
     t0, i0 = orc.image_to_patches(imgs[0], 32, 16)
     assert info == [tuple(i0)] * 2 and np.array_equal(tiles[: t0.shape[0]], t0)
-    back = harness.patches_to_image(m, tiles, info, 32, 16)
+    back = harness.patches_to_image(tiles, info, 32, 16)                       # tiling.py:143
     assert back.shape == (2, 128, 96)
     assert np.abs(back[0] - orc.patches_to_image(t0, i0, 32, 16)).max() < 1e-6
     rec = harness.reconstruct_from_patches(m, tiles, info)
     assert np.array_equal(rec, m.reconstruct(imgs))              # same chain as the slice entry point, bit for bit
     with pytest.raises(ValueError):
-        harness.image_to_patches(m, imgs, 32, 8)
+        harness.image_to_patches(imgs, 32, 8)

@@ -116,3 +116,88 @@ def test_every_f16x3_instance_gives_the_same_bits():
     _lib.check(d._lib.msiren_set_streams(d._h, 2))                   # two streams: the register-resident trunk
     assert np.array_equal(d.forward_mods(mods), ref)
     _lib.check(d._lib.msiren_set_streams(d._h, 1))
+
+
+# ---- domain guard of the split-fp16 trunk (include/msiren.h: MSIREN_E_RANGE, msiren_range_events) ----------------------------
+def _range_events(m):
+    import ctypes as C
+    from mri_inr_amd import _lib
+    n = C.c_int64()
+    _lib.check(m._lib.msiren_range_events(m._h, C.byref(n)))
+    return n.value
+
+
+@pytest.mark.parametrize("forced", ["default", "ws", "n"])
+@pytest.mark.parametrize("wscale,mod", [(1e-3, 1e3), (1e-3, 1e5), (1.0, 1e3), (1.0, 1e5), (1e3, 1e3), (1e3, 1e5), (1.0, 3e7)])
+def test_f16x3_domain_correct_or_loud(wscale, mod, forced):
+    """Modulations are ReLU outputs of trained weights: unbounded in principle.  The split-fp16 trunk carries activation x
+    modulation x 2^-a (the next layer's weight scale) in fp16: beyond 65504 it would return inf / NaN where the reference's
+    fp32 (modulated_siren.py:215-233) does not.  Whatever the magnitudes: a host-pointer call returns what the exact-fp32
+    trunk returns for the same inputs (it re-runs itself there) or meets the gate on its own; a *_dev call is reported by the
+    next sync (MSIREN_E_RANGE) -- never inf, NaN or garbage."""
+    from mri_inr_amd import _lib
+
+    L, B = 5, 40
+    sd = syn.make_state_dict(seed=11, with_encoder=False)
+    sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
+    for l in range(1, L):
+        sd[f"net.layers.{l}.weight"] = (sd[f"net.layers.{l}.weight"] * np.float32(wscale)).astype(np.float32)
+    kw = dict(dim_in=2, dim_hidden=256, dim_out=1, num_layers=L, latent_dim=256, w0=1.0, w0_initial=30.0, use_bias=True, dropout=0.1,
+              modulate=True, encoder_type="other", encoder_path=None, outer_patch_size=32, inner_patch_size=16, siren_patch_size=24,
+              device="cuda:0", activation="sine")
+    env = {"default": {}, "ws": {"MSIREN_F16_WS": "1", "MSIREN_F16_HALF": "0"}, "n": {"MSIREN_F16_WS": "0", "MSIREN_F16_HALF": "0"}}[forced]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        m = ModulatedSiren(**kw, precision="f16x3")
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    f = ModulatedSiren(**kw, precision="fp32")
+    for mm in (m, f):
+        mm.load_state_dict({k: v for k, v in sd.items() if k in mm.state_dict()}, strict=False)
+        mm.to("cuda").eval()
+    mods = (syn.make_mods(5, L, B, 256) * np.float32(mod)).astype(np.float32)
+    want = f.forward_mods(mods)                      # exact-fp32 trunk: finite for finite inputs
+    assert np.isfinite(want).all()
+    e0 = _range_events(m)
+    got = m.forward_mods(mods)                       # host-pointer call: right, by itself or through the re-run
+    assert np.isfinite(got).all()
+    flagged = _range_events(m) > e0
+    if flagged:
+        assert np.array_equal(got, want)
+    else:                                            # inside the domain: the usual gate against fp64 (relaxed to the fp32 trunk's own distance)
+        ref = orc.siren_forward(sd, mods, num_layers=L, dtype=np.float64).reshape(-1, 24, 24)
+        assert nerr(got, ref) <= max(1e-4, 3 * nerr(want, ref)), (nerr(got, ref), nerr(want, ref))
+    # the asynchronous entry point: reported at the next sync, and the handle stays usable
+    d_m = m.device_array(mods.shape).copy_from(mods)
+    d_o = m.device_array((B, 24, 24))
+    _lib.check(m._lib.msiren_forward_mods_dev(m._h, d_m.ptr, B, d_o.ptr))
+    if flagged:
+        with pytest.raises(_lib.MsirenRangeError):
+            m.sync()
+    else:
+        m.sync()
+        assert np.array_equal(d_o.numpy(), got)
+    small = syn.make_mods(6, L, 7, 256)
+    assert np.isfinite(m.forward_mods(small)).all() and _range_events(m) >= e0
+    m.sync()
+
+
+def test_f16x3_domain_nan_modulation_is_reported():
+    sd = syn.make_state_dict(seed=7)
+    m = make(sd, True)
+    mods = syn.make_mods(3, 5, 33, 256)
+    mods[2, 17, 100] = np.nan
+    from mri_inr_amd import _lib
+    d_m = m.device_array(mods.shape).copy_from(mods)
+    d_o = m.device_array((33, 24, 24))
+    _lib.check(m._lib.msiren_forward_mods_dev(m._h, d_m.ptr, 33, d_o.ptr))
+    with pytest.raises(_lib.MsirenRangeError):
+        m.sync()
+    out = m.forward_mods(mods)                       # fp32 re-run: NaN stays where the reference would have it (patch 17 only)
+    bad = ~np.isfinite(out).reshape(33, -1).all(axis=1)
+    assert bad[17] and bad.sum() == 1
