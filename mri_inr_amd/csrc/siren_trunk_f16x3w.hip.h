@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     // the loads, the waits and the MFMAs below are asm statements that name these registers, the compiler never sees a
     // weight value (left to the register allocator the 256 loop-carried fragments were split and spilled: 345-644 spills
     // in every formulation tried).  Arch VGPRs (accumulators, B fragments, epilogue) stay the compiler's.
-    const unsigned woff = (unsigned)lane * 16u;
+    const unsigned woff = (unsigned)lane * 16u, woff2 = woff + 32768u;  // tiles 0, 1 / tiles 2, 3 (the next 32 KB chunk)
     // chunk (layer l, 32-feature tile T) of the stream is 32 KB: [k-step s][sub-tile u][hi|lo][lane][8]; this wave's
     // tiles t = 0..3 are (T = 2 wave + (t >> 1), u = t & 1)
     auto wlayer = [&](int l) -> const unsigned char* {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
 #define MSIREN_WS_LOAD1(S, T, HL, WB)                                                                                  \
     asm volatile("global_load_dwordx4 a[%2:%3], %0, %1 offset:%4"                                                      \
                  :                                                                                                     \
-                 : "v"(woff), "s"((WB) + ((T) >> 1) * 32768 + (S) * 4096), "n"(MSIREN_WS_A(S, T, HL)),                 \
+                 : "v"((T) < 2 ? woff : woff2), "s"((WB) + (S) * 4096), "n"(MSIREN_WS_A(S, T, HL)),                    \
                    "n"(MSIREN_WS_A(S, T, HL) + 3), "n"(((T) & 1) * 2048 + (HL) * 1024)                                \
                  : "memory")
 // k-step S's fragments have landed once at most 8 (7 - S) younger loads are outstanding (loads return in order; any
@@ -254,6 +254,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     // modulation rows of one unit: this wave's 64 features of the L rows (L <= 8), scaled, into table rows (r0 + l) mod NR.
     // Lane (row = lane >> 4, i = lane & 15) moves features 4i..4i+3 of rows `row` and 4 + `row`: two loads, 8 registers.
     float msc0 = 1.f, msc1 = 1.f;  // mscaleT[q], mscaleT[4 + q]: set once the tables are in LDS
+    // last_layer.weight of the four features a lane stages (kept in registers: an LDS read at a slot boundary costs its
+    // whole latency, and the wait for it also waits for the B fragments prefetched for the next slot)
+    const f32x4 wrow = *reinterpret_cast<const f32x4*>(p.wout + wave * 64 + n16 * 4);
     // (global addresses below are a wave-uniform base + a 32-bit per-lane byte offset: one VGPR instead of a 64-bit pair)
     // Rows beyond L are clamped (read, not stored).  The loads are asm with a counted wait of their own: the compiler's wait
     // for a load of its own is vmcnt(0) here (it cannot see the weight loads), i.e. a drain of everything in flight.
@@ -269,8 +272,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         ra = ra >= NR ? ra - NR : ra;
         rb = rb >= NR ? rb - NR : rb;
         rb = rb >= NR ? rb - NR : rb;
-        const f32x4 ma = m[0] * msc0, mb = m[1] * msc1;
+        f32x4 ma = m[0] * msc0, mb = m[1] * msc1;
         if ((f16_out_of_range(ma) || f16_out_of_range(mb)) && p.status) *p.status = 1;  // (clamped rows repeat a checked one)
+        // the final layer's row only ever meets last_layer.weight (its scale is 1): the table holds the product
+        if (q == L - 1) ma *= wrow;
+        if (4 + q == L - 1) mb *= wrow;
         if (q < L) *reinterpret_cast<f32x4*>(modsW + (slot_unit * NR + ra) * 1024 + n16 * 16) = ma;
         if (4 + q < L) *reinterpret_cast<f32x4*>(modsW + (slot_unit * NR + rb) * 1024 + n16 * 16) = mb;
     };
@@ -448,16 +454,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     // instructions later.
     unsigned ehu[2][2][4], elu[2][2][4];  // 16-byte pieces being assembled: [column group g][k-step 2 wave + u][4 x (2 x f16)]
     f32x4 em[4];          // modulation of the prev slot's layer, per tile
-    f32x4 ew[4];          // last_layer.weight per tile (final slots)
-    f32x4 mw[4];          // final slots: modulation x last_layer.weight, per tile
+    f32x4 mw[4];          // final slots: modulation x last_layer.weight, per tile (the final row of the table holds the product)
     f32x4 em0_[4];        // layer-0 modulation row of the unit being produced (final slots)
     float part[2] = {0.f, 0.f};
     float sv0_ = 0.f, sv1_ = 0.f;
     f32x4 raw0[4][2];     // layer-0 table values of the unit being produced (final slots)
     unsigned l0h_[4], l0l_[4];
 #define MSIREN_WS_LD_EM(T) em[T] = *reinterpret_cast<const f32x4*>(emr_ + (T) * 64)
-#define MSIREN_WS_LD_EW(T) ew[T] = *reinterpret_cast<const f32x4*>(woutL + (T) * 64)
-#define MSIREN_WS_LD_MW(T) mw[T] = *reinterpret_cast<const f32x4*>(emr_ + (T) * 64) * *reinterpret_cast<const f32x4*>(woutL + (T) * 64)
+#define MSIREN_WS_LD_MWT(T) mw[T] = *reinterpret_cast<const f32x4*>(emr_ + (T) * 64) /* final row: modulation x last_layer.weight */
 #define MSIREN_WS_LD_EM0(T) em0_[T] = *reinterpret_cast<const f32x4*>(em0r_ + (T) * 64)
 #define MSIREN_WS_S0(T, G, HH)                                                                                       \
     do {                                                                                                             \
@@ -532,8 +536,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     } while (0)
 #define MSIREN_WS_PRE_B(S)                                                                                           \
     do {                                                                                                             \
-        if ((S) == 0) { MSIREN_WS_LD_EM(0); MSIREN_WS_LD_EW(0); MSIREN_WS_LD_EM(1); MSIREN_WS_LD_EW(1);              \
-                        MSIREN_WS_LD_EM(2); MSIREN_WS_LD_EW(2); MSIREN_WS_LD_EM(3); MSIREN_WS_LD_EW(3);              \
+        if ((S) == 0) { MSIREN_WS_LD_MWT(0); MSIREN_WS_LD_MWT(1); MSIREN_WS_LD_MWT(2); MSIREN_WS_LD_MWT(3);          \
                         l0_load_half(l0c0_, 0, raw0); }                                                              \
         if ((S) == 2) { MSIREN_WS_LD_EM0(0); MSIREN_WS_LD_EM0(1); l0_load_half(l0c0_, 1, raw0); }                    \
         if ((S) == 3) { MSIREN_WS_LD_EM0(2); MSIREN_WS_LD_EM0(3); }                                                  \
@@ -640,8 +643,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         /* ---- slot boundary ---- */                                                                                \
         /* (the prev final slot's output was finished in this slot's region 7) */                                   \
         if (pv_final && pv_out) fin_par ^= 1;                                                                        \
-        if (stage_mods) { /* (fetched a slot ago; behind it at most this slot's 64 weight loads and 8 table loads) */ \
+        if (stage_mods) { /* (fetched a slot ago; behind it at most this slot's 64 weight loads, 8 table loads and, youngest, */ \
+            /* a final body's output store -- which must NOT be waited for: a store takes ~1000 cycles to be acknowledged) */ \
             if ((FL) == 2) asm volatile("s_waitcnt vmcnt(63)" : "+v"(mnext[0]), "+v"(mnext[1]));                     \
+            else if (pv_final) asm volatile("s_waitcnt vmcnt(1)" : "+v"(mnext[0]), "+v"(mnext[1]));                  \
             else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mnext[0]), "+v"(mnext[1]));                                \
             int r0n = row0 + L;                                                                                      \
             r0n = r0n >= NR ? r0n - NR : r0n;                                                                        \
@@ -649,8 +654,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         }                                                                                                            \
         /* pass-id pipeline: the atomic is issued at the pass boundary, its result written to LDS one slot later (no */ \
         /* wait on the way), read by everybody another slot later (a barrier in between); needed from the final layer on */ \
-        if (k_in_pass == 0) { /* the atomic was issued a whole slot ago */                                           \
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(fetched_id));                                                   \
+        if (k_in_pass == 0) { /* the atomic was issued a whole slot ago; the body since was a final one (a pass's first */ \
+            /* slot follows a final-layer slot): its output store is the one younger operation */                   \
+            asm volatile("s_waitcnt vmcnt(1)" : "+v"(fetched_id));                                                   \
             if (tid == 0) qslot[0] = (int)((unsigned)fetched_id - p.pass_base) + (int)gridDim.x;                     \
         }                                                                                                            \
         if (k_in_pass == 1) {                                                                                        \
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         const unsigned char* const emr_ = modsL + (pv_unit * NR + pv_mrow) * 1024;
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs (asm) are still writing the accumulators read below
 #pragma unroll
-        for (int t = 0; t < 4; ++t) MSIREN_WS_LD_MW(t);
+        for (int t = 0; t < 4; ++t) MSIREN_WS_LD_MWT(t);
         float pr[2] = {0.f, 0.f};
         // the last slot's accumulators, by name (parity pp is a run-time value here: both candidates are read, one is kept)
 #define MSIREN_WS_DRAIN1(T, G, E)                                                                                      \
