@@ -104,15 +104,16 @@ def effective_cores() -> int:
 
 def traffic_bytes(kernel):
     """HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes (collected with
-    tools/profile.sh: separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction); None if the
-    profile on record is for another kernel."""
+    tools/profile.sh: separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction); None if no profile on
+    record is for this kernel."""
     for rnd in ("r3", "r2", "r1"):
         try:
             d = json.load(open(os.path.join(REPO, "profiles", rnd, "traffic.json")))
         except Exception:
             continue
-        if d.get("kernel") == kernel:
-            return d["bytes_per_launch"]
+        for e in d.get("kernels", [d]):
+            if e.get("kernel") == kernel:
+                return e["bytes_per_launch"]
     return None
 
 

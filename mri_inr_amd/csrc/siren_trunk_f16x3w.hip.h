@@ -326,8 +326,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
                 split_products_pk(a0[2], m0[2], a0[3], m0[3], h1, l1);
                 split_products_pk(a1[0], m1[0], a1[1], m1[1], h2, l2);
                 split_products_pk(a1[2], m1[2], a1[3], m1[3], h3, l3);
-                *reinterpret_cast<h8*>(img + u * 4096 + (2 * g) * 1024) = pack_h8(h0, h1, h2, h3);
-                *reinterpret_cast<h8*>(img + u * 4096 + (2 * g + 1) * 1024) = pack_h8(l0, l1, l2, l3);
+                h8 ph = pack_h8(h0, h1, h2, h3), pl = pack_h8(l0, l1, l2, l3);
+                asm volatile("s_nop 0" : "+v"(ph), "+v"(pl));  // (a half-register write is not stored by the very next instruction)
+                *reinterpret_cast<h8*>(img + u * 4096 + (2 * g) * 1024) = ph;
+                *reinterpret_cast<h8*>(img + u * 4096 + (2 * g + 1) * 1024) = pl;
             }
         }
     };
@@ -463,20 +465,33 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
 #define MSIREN_WS_LD_EM(T) em[T] = *reinterpret_cast<const f32x4*>(emr_ + (T) * 64)
 #define MSIREN_WS_LD_MWT(T) mw[T] = *reinterpret_cast<const f32x4*>(emr_ + (T) * 64) /* final row: modulation x last_layer.weight */
 #define MSIREN_WS_LD_EM0(T) em0_[T] = *reinterpret_cast<const f32x4*>(em0r_ + (T) * 64)
+// sine: S0, S1 = one v_sin_f32 each.  Morlet, sin(2 pi r) * exp2(cg r^2) (the products in activate<1>'s order): both
+// elements in S0 -- ten instructions straight from the accumulator registers, the two chains interleaved so that no
+// transcendental's result is read by the instruction behind it -- and S1 empty.
 #define MSIREN_WS_S0(T, G, HH)                                                                                       \
     do {                                                                                                             \
         if constexpr (ACT == 0) asm volatile("v_sin_f32 %0, v[%1]" : "=v"(sv0_) : "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH))); \
-        else { float r_; asm volatile("v_mov_b32 %0, v[%1]" : "=v"(r_) : "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH))); sv0_ = activate<ACT>(r_, p.cg); } \
+        else {                                                                                                       \
+            float t0_, t1_;                                                                                          \
+            asm volatile("v_sin_f32 %0, v[%5]\n\tv_sin_f32 %1, v[%6]\n\t"                                            \
+                         "v_mul_f32 %2, %4, v[%5]\n\tv_mul_f32 %3, %4, v[%6]\n\t"                                    \
+                         "v_mul_f32 %2, %2, v[%5]\n\tv_mul_f32 %3, %3, v[%6]\n\t"                                    \
+                         "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"                                                  \
+                         "v_mul_f32 %0, %0, %2\n\tv_mul_f32 %1, %1, %3"                                              \
+                         : "=&v"(sv0_), "=&v"(sv1_), "=&v"(t0_), "=&v"(t1_)                                          \
+                         : "v"(p.cg), "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH)), "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH) + 1)); \
+        }                                                                                                            \
     } while (0)
 #define MSIREN_WS_S1(T, G, HH)                                                                                       \
     do {                                                                                                             \
         if constexpr (ACT == 0) asm volatile("v_sin_f32 %0, v[%1]" : "=v"(sv1_) : "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH) + 1)); \
-        else { float r_; asm volatile("v_mov_b32 %0, v[%1]" : "=v"(r_) : "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH) + 1)); sv1_ = activate<ACT>(r_, p.cg); } \
     } while (0)
 #define MSIREN_WS_MIXH0(DST, A, M) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(DST) : "v"(A), "v"(M))
 #define MSIREN_WS_MIXH1(DST, A, M) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(DST) : "v"(A), "v"(M))
 #define MSIREN_WS_MIXL0(DST, A, M, HI) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(DST) : "v"(A), "v"(M), "v"(HI))
 #define MSIREN_WS_MIXL1(DST, A, M, HI) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(DST) : "v"(A), "v"(M), "v"(HI))
+// the last half-register write of a 16-byte piece: the ds_write that takes the piece may be scheduled right behind it
+#define MSIREN_WS_MIXL1_LAST(DST, A, M, HI) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 0" : "+v"(DST) : "v"(A), "v"(M), "v"(HI))
     // a finished 16-byte piece pair (hi, lo) -> the unit image, k-step 2 wave + U, column group G
 #define MSIREN_WS_STORE_PIECE(HI, LO, U, G)                                                                          \
     do {                                                                                                             \
