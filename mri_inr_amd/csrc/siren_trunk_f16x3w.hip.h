@@ -490,6 +490,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
 #define MSIREN_WS_MIXH1(DST, A, M) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(DST) : "v"(A), "v"(M))
 #define MSIREN_WS_MIXL0(DST, A, M, HI) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(DST) : "v"(A), "v"(M), "v"(HI))
 #define MSIREN_WS_MIXL1(DST, A, M, HI) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(DST) : "v"(A), "v"(M), "v"(HI))
+// both halves of a register in one statement (two plain VALU in one gap; fewer statement boundaries for the compiler to pad)
+#define MSIREN_WS_MIXH01(DST, A0, M0, A1, M1)                                                                        \
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]\n\tv_fma_mixhi_f16 %0, %3, %4, 0 op_sel_hi:[0,0,0]"  \
+                 : "=&v"(DST) : "v"(A0), "v"(M0), "v"(A1), "v"(M1))
+#define MSIREN_WS_MIXL01(DST, A0, M0, A1, M1, HI)                                                                    \
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%5 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"                              \
+                 "v_fma_mixhi_f16 %0, %3, %4, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]"                                  \
+                 : "=&v"(DST) : "v"(A0), "v"(M0), "v"(A1), "v"(M1), "v"(HI))
+#define MSIREN_WS_MIXL01_LAST(DST, A0, M0, A1, M1, HI)                                                               \
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%5 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"                              \
+                 "v_fma_mixhi_f16 %0, %3, %4, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 0"                        \
+                 : "=&v"(DST) : "v"(A0), "v"(M0), "v"(A1), "v"(M1), "v"(HI))
 // the last half-register write of a 16-byte piece: the ds_write that takes the piece may be scheduled right behind it
 #define MSIREN_WS_MIXL1_LAST(DST, A, M, HI) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\ts_nop 0" : "+v"(DST) : "v"(A), "v"(M), "v"(HI))
     // a finished 16-byte piece pair (hi, lo) -> the unit image, k-step 2 wave + U, column group G

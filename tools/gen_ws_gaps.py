@@ -5,6 +5,9 @@ of 192 gaps per slot (8 k-step regions x 24 MFMAs); written out by hand in macro
 conditionals per gap x 2304 gaps and the compiler ran out of memory.  Re-run after changing the schedule; the output is
 committed."""
 import os
+import sys
+
+PAIRS = "--pairs" in sys.argv   # both halves of a packed register in one statement (5 gaps per half accumulator instead of 7)
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mri_inr_amd", "csrc", "siren_trunk_f16x3w_gaps.hip.h")
 A, B = {}, {}
@@ -24,6 +27,10 @@ def half_a(j0, t, g, hh, last=False):
     e = f"[{g}]{idx(t, hh)}"
     put(A, j0, f"MSIREN_WS_S0({t}, {g}, {hh})")
     put(A, j0 + 1, f"MSIREN_WS_S1({t}, {g}, {hh})")
+    if PAIRS:
+        put(A, j0 + 2, f"MSIREN_WS_MIXH01(ehu{e}, sv0_, em[{t}][{2 * hh}], sv1_, em[{t}][{2 * hh + 1}])")
+        put(A, j0 + 4, f"MSIREN_WS_MIXL01{'_LAST' if last else ''}(elu{e}, sv0_, em[{t}][{2 * hh}], sv1_, em[{t}][{2 * hh + 1}], ehu{e})")
+        return
     put(A, j0 + 2, f"MSIREN_WS_MIXH0(ehu{e}, sv0_, em[{t}][{2 * hh}])")
     put(A, j0 + 3, f"MSIREN_WS_MIXH1(ehu{e}, sv1_, em[{t}][{2 * hh + 1}])")
     put(A, j0 + 5, f"MSIREN_WS_MIXL0(elu{e}, sv0_, em[{t}][{2 * hh}], ehu{e})")
@@ -67,6 +74,10 @@ for u, g in ((0, 0), (0, 1), (1, 0), (1, 1)):   # layer 0 of the next pass: hi h
         put(B, j - 1, f"MSIREN_WS_RAW0_WAIT(FL, 1, {younger_weight_loads(2, j - 1)}, 0)")
     for k in range(4):
         t, e = 2 * u + (k >> 1), 2 * (k & 1)
+        if PAIRS:
+            put(B, j + 2 * k, f"MSIREN_WS_MIXH01(l0h_[{k}], raw0[{t}][{g}][{e}], em0_[{t}][{e}], raw0[{t}][{g}][{e + 1}], em0_[{t}][{e + 1}])")
+            put(B, j + 8 + 2 * k, f"MSIREN_WS_MIXL01{'_LAST' if k == 3 else ''}(l0l_[{k}], raw0[{t}][{g}][{e}], em0_[{t}][{e}], raw0[{t}][{g}][{e + 1}], em0_[{t}][{e + 1}], l0h_[{k}])")
+            continue
         put(B, j + 2 * k, f"MSIREN_WS_MIXH0(l0h_[{k}], raw0[{t}][{g}][{e}], em0_[{t}][{e}])")
         put(B, j + 2 * k + 1, f"MSIREN_WS_MIXH1(l0h_[{k}], raw0[{t}][{g}][{e + 1}], em0_[{t}][{e + 1}])")
         put(B, j + 8 + 2 * k, f"MSIREN_WS_MIXL0(l0l_[{k}], raw0[{t}][{g}][{e}], em0_[{t}][{e}], l0h_[{k}])")
