@@ -22,6 +22,7 @@
 
 #include "../../include/msiren.h"
 #include "encoder_modulator.hip.h"
+#include "modulator_chain.hip.h"
 #include "pass_queue.h"
 #include "weights_blob.h"
 #include "siren_trunk_f16x3.hip.h"
@@ -96,6 +97,14 @@ struct msiren_ctx {
     bool f16_off = false;          // the call in flight is the exact-fp32 re-run of a host-pointer call
     int64_t range_events = 0;      // launches that raised the flag (re-run or reported) since create
     float* d_dump = nullptr;       // 256 floats: where lanes of the weight-stationary trunk that have nothing to store write
+    // modulator chain (modulator_chain.hip.h): conv3, Linear(64, Z) and the Modulator layers in one launch, single-stream handles
+    int chain_on = 1;              // MSIREN_CHAIN=0: per-layer launches (read at create)
+    unsigned* d_chain_ctr = nullptr;                 // [chain_clusters][CHAIN_STAGES] stage counters, never reset
+    unsigned chain_base[msiren::CHAIN_STAGES] = {};  // what every cluster's counters hold (host's count)
+    int chain_clusters = 0;
+    unsigned chain_spin = 400000;  // MSIREN_CHAIN_SPIN (tests: 0 = give up at the first poll that finds the stage unfinished)
+    bool chain_rerun_pending = false;
+    int64_t chain_events = 0;      // launches that gave up a hand-off wait (chain switched off for the handle afterwards)
     int f16_ws = 1;                // the weight-stationary trunk runs single-stream launches (MSIREN_F16_WS=0: never; read at create)
     float *d_bias16 = nullptr, *d_wout16 = nullptr, *d_s0t = nullptr;
     float winv16[16] = {0};    // 32x32 kernel: exact inverse of each hidden layer's power-of-two weight scale
@@ -969,9 +978,71 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
     return 0;
 }
 
+// ---- the Linear layers of encoder tail + modulator as one launch (modulator_chain.hip.h) -----------------------------
+// Single-stream handles only: the grid (<= one workgroup per CU) must be resident as a whole, which it is when the
+// stream's previous kernel has finished and no other stream of the handle is running a persistent trunk.
+bool use_chain(msiren_ctx* h, int64_t B) {
+    // H % 128: a batch of 8 k-blocks never straddles the [hidden ; latent] seam of a Modulator layer's input
+    return h->chain_on && h->d_chain_ctr && h->chain_clusters > 0 && h->nstreams == 1 && !h->overlap && h->H % 128 == 0 &&
+           h->Z % 16 == 0 && h->L + 2 <= msiren::CHAIN_STAGES && B <= 131072;
+}
+
+void chain_add_modulator_stages(msiren_ctx* h, msiren::ChainParams& cp, const float* z_dev, int64_t B, float* mods_dev) {
+    size_t off = 0;
+    for (int l = 0; l < h->L; ++l) {
+        const int Kh = (l == 0 ? 0 : h->H);
+        msiren::ChainStage& st = cp.st[cp.nstages++];
+        st.w = h->d_modw_rm + off;
+        st.bias = h->d_modb + (size_t)l * h->H;
+        st.a = l == 0 ? nullptr : mods_dev + (size_t)(l - 1) * B * h->H;
+        st.b = z_dev;
+        st.out = mods_dev + (size_t)l * B * h->H;
+        st.H = h->H;
+        st.Ka = Kh;
+        st.Kb = h->Z;
+        st.act = msiren::LIN_ACT_RELU;
+        off += (size_t)(Kh + h->Z) * h->H;
+    }
+}
+
+int launch_chain(msiren_ctx* h, msiren::ChainParams& cp, int64_t B) {
+    cp.B = (int)B;
+    const int groups = (int)((B + 15) / 16);
+    cp.gpc = (groups + h->chain_clusters - 1) / h->chain_clusters;
+    cp.ctr = h->d_chain_ctr;
+    cp.count = h->plan;
+    cp.gave_up = h->status_dev + 1;
+    cp.spin_limit = h->chain_spin;  // polls (s_sleep + one L2 round trip each): a few tenths of a second
+    for (int s = 0; s < cp.nstages; ++s) cp.base[s] = h->chain_base[s];
+    hipLaunchKernelGGL(msiren::modulator_chain_kernel, dim3((unsigned)(h->chain_clusters * msiren::CHAIN_MEMBERS)), dim3(256), 0,
+                       h->sc[h->cur].s, cp);
+    HIPCHK(hipGetLastError());
+    // every cluster's active members add 1 per stage, whether or not the cluster has rows
+    for (int s = 0; s < cp.nstages; ++s) h->chain_base[s] += (unsigned)std::min(cp.st[s].H / 16, msiren::CHAIN_MEMBERS);
+    return 0;
+}
+
+// a chain launch gave up a wait (the flag is raised by the kernel): its outputs and everything computed from them are
+// not valid.  Counters back to zero, chain off for this handle -- the per-layer launches take over.
+bool take_chain_flag(msiren_ctx* h) {
+    if (!h->status_host || !h->status_host[1]) return false;
+    h->status_host[1] = 0;
+    h->chain_events++;
+    h->chain_on = 0;
+    h->chain_rerun_pending = true;
+    (void)hipMemset(h->d_chain_ctr, 0, (size_t)h->chain_clusters * msiren::CHAIN_STAGES * sizeof(unsigned));
+    for (auto& b : h->chain_base) b = 0;
+    return true;
+}
+
 int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_dev) {
     if (B == 0) return 0;
     if (!h->have_modulator) return fail(MSIREN_E_STATE, "modulator.* weights were not loaded");
+    if (use_chain(h, B)) {
+        msiren::ChainParams cp{};
+        chain_add_modulator_stages(h, cp, z_dev, B, mods_dev);
+        return launch_chain(h, cp, B);
+    }
     size_t off = 0;
     const bool mfma_ok = (h->H % 16 == 0) && (h->Z % 16 == 0);
     for (int l = 0; l < h->L && mfma_ok; ++l) {
@@ -1060,6 +1131,45 @@ int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_de
     return 0;
 }
 
+// encoder + modulator: tiles -> latent -> modulations.  With the chain: conv1+conv2 per tile, then ONE launch for
+// conv3, Linear(64, Z) and the Modulator layers (3 launches per forward with the trunk); small batches keep the fused
+// per-tile encoder and chain the Modulator layers only.
+int launch_encoder_modulator(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_dev, float* mods_dev) {
+    if (B == 0) return 0;
+    if (!(use_chain(h, B) && h->have_encoder && h->have_modulator && B >= 48)) {
+        int rc = launch_encoder(h, tiles_dev, B, z_dev);
+        if (rc) return rc;
+        return launch_modulator(h, z_dev, B, mods_dev);
+    }
+    auto& c = h->sc[h->cur];
+    int rc = ensure(h, c.feat, (size_t)B * (2048 + 64) * sizeof(float));
+    if (rc) return rc;
+    float* feat = (float*)c.feat.p;
+    float* a3 = feat + (size_t)B * 2048;
+    h->enc.plan = h->plan;
+    hipLaunchKernelGGL(msiren::encoder_conv_kernel, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, feat);
+    HIPCHK(hipGetLastError());
+    msiren::ChainParams cp{};
+    msiren::ChainStage& c3 = cp.st[cp.nstages++];
+    c3.w = h->d_c3w_rm;
+    c3.bias = h->enc.c3b;
+    c3.b = feat;
+    c3.out = a3;
+    c3.H = 64;
+    c3.Kb = 2048;
+    c3.act = msiren::LIN_ACT_LEAKY02;
+    msiren::ChainStage& fc = cp.st[cp.nstages++];
+    fc.w = h->d_fcw_rm;
+    fc.bias = h->enc.fcb;
+    fc.b = a3;
+    fc.out = z_dev;
+    fc.H = h->Z;
+    fc.Kb = 64;
+    fc.act = msiren::LIN_ACT_NONE;
+    chain_add_modulator_stages(h, cp, z_dev, B, mods_dev);
+    return launch_chain(h, cp, B);
+}
+
 int forward_latent_dev(msiren_ctx* h, const float* z_dev, int64_t B, float* out_dev, float* mods_out_dev) {
     float* mods = mods_out_dev;
     if (!mods) {
@@ -1075,9 +1185,12 @@ int forward_latent_dev(msiren_ctx* h, const float* z_dev, int64_t B, float* out_
 int forward_tiles_dev(msiren_ctx* h, const float* tiles_dev, int64_t B, float* out_dev) {
     int rc = ensure(h, h->sc[h->cur].latent, (size_t)B * h->Z * sizeof(float));
     if (rc) return rc;
-    rc = launch_encoder(h, tiles_dev, B, (float*)h->sc[h->cur].latent.p);
+    rc = ensure(h, h->sc[h->cur].mods, (size_t)h->L * B * h->H * sizeof(float));
     if (rc) return rc;
-    return forward_latent_dev(h, (const float*)h->sc[h->cur].latent.p, B, out_dev, nullptr);
+    float* mods = (float*)h->sc[h->cur].mods.p;
+    rc = launch_encoder_modulator(h, tiles_dev, B, (float*)h->sc[h->cur].latent.p, mods);
+    if (rc) return rc;
+    return launch_trunk(h, mods, B, out_dev);
 }
 
 // the f16x3 domain guard's flag: set by a trunk launch that met a scaled modulation beyond fp16 (or a NaN / inf)
@@ -1091,6 +1204,10 @@ bool take_range_flag(msiren_ctx* h) {
 int sync_all(msiren_ctx* h) {
     for (auto& c : h->sc)
         if (c.s) HIPCHK(hipStreamSynchronize(c.s));
+    if (take_chain_flag(h))
+        return fail(MSIREN_E_HIP, "the modulator chain launch gave up waiting for a hand-off between its workgroups (its grid was not "
+                                  "resident as a whole: is another process holding CUs of this device?): the outputs of the calls since the "
+                                  "last sync are not valid.  The handle now uses one launch per layer; re-issue the calls");
     if (!h->f16_off && take_range_flag(h))
         return fail(MSIREN_E_RANGE, "a modulation (times the layer's power-of-two weight scale) exceeds what the split-fp16 trunk's fp16 "
                                     "operands can carry (65504), or is not finite: the outputs of the calls since the last sync are not valid. "
@@ -1104,6 +1221,10 @@ int sync_all(msiren_ctx* h) {
 template <typename F>
 int with_range_fallback(msiren_ctx* h, F&& run) {
     int rc = run();
+    if (rc == MSIREN_E_HIP && h->chain_events && !h->chain_on && h->chain_rerun_pending) {  // the chain gave up: per-layer launches now
+        h->chain_rerun_pending = false;
+        rc = run();
+    }
     if (rc == MSIREN_E_RANGE || (rc == 0 && take_range_flag(h))) {
         h->f16_off = true;
         rc = run();
@@ -1271,14 +1392,22 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_HOST_CHUNKS")) h->host_chunks = std::max(1, std::min(std::atoi(e), 16));
     if (const char* e = std::getenv("MSIREN_QUEUE_START")) h->queue_start = (unsigned)std::strtoul(e, nullptr, 0);
     if (const char* e = std::getenv("MSIREN_F16_WS")) h->f16_ws = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_CHAIN")) h->chain_on = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_CHAIN_SPIN")) h->chain_spin = (unsigned)std::strtoul(e, nullptr, 0);
+    h->chain_clusters = std::min(16, h->cus_limit / msiren::CHAIN_MEMBERS);  // at most one workgroup per CU: the whole grid is resident
     declare_expected(h);
     hipError_t e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->sc[0].s, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->sc[1].s, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->status_host, 64, hipHostMallocMapped);
     if (e == hipSuccess) {
-        *h->status_host = 0;
+        h->status_host[0] = h->status_host[1] = 0;  // [0] f16x3 domain guard, [1] modulator chain gave up a wait
         e = hipHostGetDevicePointer((void**)&h->status_dev, (void*)h->status_host, 0);
+    }
+    if (e == hipSuccess && h->chain_clusters > 0) {
+        const size_t nb = (size_t)h->chain_clusters * msiren::CHAIN_STAGES * sizeof(unsigned);
+        e = hipMalloc((void**)&h->d_chain_ctr, nb);
+        if (e == hipSuccess) e = hipMemset(h->d_chain_ctr, 0, nb);
     }
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
@@ -1297,6 +1426,7 @@ int msiren_destroy(msiren_handle h) {
         if (c.s) (void)hipStreamSynchronize(c.s);
     if (h->comm) (void)msiren_comm_destroy(h);
     if (h->status_host) (void)hipHostFree((void*)h->status_host);
+    if (h->d_chain_ctr) (void)hipFree(h->d_chain_ctr);
     if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
     if (h->d_wp16) (void)hipFree(h->d_wp16);
     if (h->d_wp16n) (void)hipFree(h->d_wp16n);
@@ -1545,8 +1675,7 @@ static int reconstruct_tiles_on_current_stream(msiren_handle h, const float* pat
     hipLaunchKernelGGL(msiren::compact_flags_kernel, dim3(1), dim3(256), 0, st, black, (int)NP, (h->P + 31) / 32, plan);
     HIPCHK(hipGetLastError());
     h->plan = plan;
-    rc = launch_encoder(h, patches, NP, (float*)h->sc[h->cur].latent.p);
-    if (!rc) rc = launch_modulator(h, (const float*)h->sc[h->cur].latent.p, NP, (float*)h->sc[h->cur].mods.p);
+    rc = launch_encoder_modulator(h, patches, NP, (float*)h->sc[h->cur].latent.p, (float*)h->sc[h->cur].mods.p);
     if (!rc) rc = launch_trunk(h, (const float*)h->sc[h->cur].mods.p, NP, rec);
     h->plan = nullptr;
     if (rc) return rc;
@@ -2008,6 +2137,13 @@ int msiren_comm_destroy(msiren_handle h) {
     h->comm = nullptr;
     h->comm_n = 1;
     h->comm_rank = 0;
+    return 0;
+}
+
+int msiren_chain_info(msiren_handle h, int32_t* active, int64_t* events) {
+    if (!h || !active || !events) return fail(MSIREN_E_INVALID, "null argument");
+    *active = (h->chain_on && h->d_chain_ctr && h->chain_clusters > 0 && h->nstreams == 1) ? 1 : 0;
+    *events = h->chain_events;
     return 0;
 }
 
