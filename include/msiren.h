@@ -253,15 +253,19 @@ MSIREN_API int msiren_device_count(int32_t* count);
  * The reference's fp32 arithmetic (modulated_siren.py:215-233) has no such bound; this is what keeps "auto" precision from
  * returning inf / NaN where it would not.  msiren_range_events: launches that raised the flag since msiren_create. */
 MSIREN_API int msiren_range_events(msiren_handle h, int64_t* count);
-/* The Linear layers between the encoder's convolutions and the trunk -- conv3 == Linear(2048, 64), Linear(64, Z) and the L
- * Modulator layers, `self.modulator(self.encoder(tiles))` of modulated_siren.py:446 -- run as ONE launch on single-stream
- * handles (workgroups hand a layer's output to the next layer's workgroups inside the launch; bit-identical to one launch
- * per layer, which handles with two streams keep).  A launch that had to give up a hand-off wait (its grid was not
- * resident as a whole) raises a flag: a host-pointer call then runs itself again with one launch per layer; after *_dev
- * calls the next msiren_sync returns MSIREN_E_HIP (outputs since the previous sync are not valid).  Either way the handle
- * uses one launch per layer from then on.  *active: 1 while the handle would use the single launch; *events: launches that
- * gave up, since msiren_create. */
+/* Opt-in (environment MSIREN_CHAIN=1 when the handle is created; single-stream handles, batches up to 512 tiles): the
+ * Linear layers between the encoder's convolutions and the trunk -- conv3 == Linear(2048, 64), Linear(64, Z) and the L
+ * Modulator layers, `self.modulator(self.encoder(tiles))` of modulated_siren.py:446 -- run as ONE launch (3 launches per
+ * forward instead of 9).  Workgroups hand a layer's output to the next layer's workgroups inside the launch; results are
+ * bit-identical to one launch per layer.  Measured no faster than the launches it replaces, hence
+ * not the default.  A launch that had to give up a hand-off wait (its grid was not resident as a whole) raises a flag: a
+ * host-pointer call then runs itself again with one launch per layer; after *_dev calls the next msiren_sync returns
+ * MSIREN_E_HIP (outputs since the previous sync are not valid).  Either way the handle uses one launch per layer from
+ * then on.  *active: 1 while the handle would use the single launch; *events: launches that gave up, since msiren_create. */
 MSIREN_API int msiren_chain_info(msiren_handle h, int32_t* active, int64_t* events);
+/* Diagnostic: one msiren_forward_tiles_dev whose chain launch is stamped.  stamps_host: (clusters x 16 workgroups) x 17 uint64,
+ * clusters = min(16, CUs / 16): [0] s_memrealtime (100 MHz) at the workgroup's start, [1 + s] after its stage s (0 = not run). */
+MSIREN_API int msiren_chain_timeline(msiren_handle h, const float* tiles_dev, int64_t B, float* out_dev, uint64_t* stamps_host);
 /* Algorithmic FLOPs per coordinate for the handle's configuration: 2*2*H + (L-1)*2*H*H + 2*H. */
 MSIREN_API int msiren_flops_per_coord(msiren_handle h, double* flops);
 MSIREN_API int msiren_abi_version(void);

@@ -70,6 +70,7 @@ struct msiren_ctx {
     struct StreamCtx {
         hipStream_t s = nullptr;
         DevBuf mods, modpad, latent, patches, keep, rec, queue, feat, plan;
+        DevBuf gran;  // modulator chain: stage outputs as {value, epoch} granules (zeroed when allocated)
         msiren::PassQueue pq;  // host view of the never-reset pass counter (pass_queue.h)
     } sc[2];
     int cur = 0, nstreams = 1;
@@ -98,12 +99,11 @@ struct msiren_ctx {
     int64_t range_events = 0;      // launches that raised the flag (re-run or reported) since create
     float* d_dump = nullptr;       // 256 floats: where lanes of the weight-stationary trunk that have nothing to store write
     // modulator chain (modulator_chain.hip.h): conv3, Linear(64, Z) and the Modulator layers in one launch, single-stream handles
-    int chain_on = 1;              // MSIREN_CHAIN=0: per-layer launches (read at create)
-    unsigned* d_chain_ctr = nullptr;                 // [chain_clusters][CHAIN_STAGES] stage counters, never reset
-    unsigned chain_base[msiren::CHAIN_STAGES] = {};  // what every cluster's counters hold (host's count)
+    int chain_on = 0;              // MSIREN_CHAIN=1: on (read at create).  Off by default: measured no faster than a launch per layer
     int chain_clusters = 0;
     unsigned chain_spin = 400000;  // MSIREN_CHAIN_SPIN (tests: 0 = give up at the first poll that finds the stage unfinished)
     bool chain_rerun_pending = false;
+    unsigned long long* chain_stamps = nullptr;  // set for the one launch of msiren_chain_timeline
     int64_t chain_events = 0;      // launches that gave up a hand-off wait (chain switched off for the handle afterwards)
     int f16_ws = 1;                // the weight-stationary trunk runs single-stream launches (MSIREN_F16_WS=0: never; read at create)
     float *d_bias16 = nullptr, *d_wout16 = nullptr, *d_s0t = nullptr;
@@ -981,22 +981,47 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
 // ---- the Linear layers of encoder tail + modulator as one launch (modulator_chain.hip.h) -----------------------------
 // Single-stream handles only: the grid (<= one workgroup per CU) must be resident as a whole, which it is when the
 // stream's previous kernel has finished and no other stream of the handle is running a persistent trunk.
+size_t chain_lds_bytes(const msiren_ctx* h) { return (size_t)msiren::CHAIN_GPC * 16 * (h->Z + msiren::CHAIN_ZPAD) * sizeof(float); }
+
 bool use_chain(msiren_ctx* h, int64_t B) {
     // H % 128: a batch of 8 k-blocks never straddles the [hidden ; latent] seam of a Modulator layer's input
-    return h->chain_on && h->d_chain_ctr && h->chain_clusters > 0 && h->nstreams == 1 && !h->overlap && h->H % 128 == 0 &&
-           h->Z % 16 == 0 && h->L + 2 <= msiren::CHAIN_STAGES && B <= 131072;
+    return h->chain_on && h->chain_clusters > 0 && h->nstreams == 1 && !h->overlap && h->H % 128 == 0 &&
+           h->Z % 16 == 0 && h->L + 2 <= msiren::CHAIN_STAGES && chain_lds_bytes(h) <= 64 * 1024 &&
+           B <= (int64_t)h->chain_clusters * msiren::CHAIN_GPC * 16;  // larger batches are throughput-bound: a launch per layer fills the chip
 }
 
-void chain_add_modulator_stages(msiren_ctx* h, msiren::ChainParams& cp, const float* z_dev, int64_t B, float* mods_dev) {
+// The exchange buffer of the stream: [conv3 out (B, 64)] [latent (B, Z)] [Modulator layers 0..L-2 (B, H) each], 8 bytes per
+// element.  Zeroed when (re)allocated: a granule is valid only under the launch's epoch, and epochs are never reused.
+std::atomic<unsigned> g_chain_epoch{0};
+
+int chain_exchange(msiren_ctx* h, int64_t B, unsigned long long** a3, unsigned long long** z, unsigned long long** hid) {
+    auto& c = h->sc[h->cur];
+    const size_t elems = (size_t)B * (64 + h->Z + (size_t)(h->L - 1) * h->H);
+    const void* before = c.gran.p;
+    int rc = ensure(h, c.gran, elems * 8);
+    if (rc) return rc;
+    if (c.gran.p != before) HIPCHK(hipMemsetAsync(c.gran.p, 0, c.gran.cap, c.s));
+    *a3 = (unsigned long long*)c.gran.p;
+    *z = *a3 + (size_t)B * 64;
+    *hid = *z + (size_t)B * h->Z;
+    return 0;
+}
+
+void chain_add_modulator_stages(msiren_ctx* h, msiren::ChainParams& cp, const float* z_dev, const unsigned long long* z_gran,
+                                unsigned long long* hid, int64_t B, float* mods_dev) {
     size_t off = 0;
     for (int l = 0; l < h->L; ++l) {
         const int Kh = (l == 0 ? 0 : h->H);
         msiren::ChainStage& st = cp.st[cp.nstages++];
         st.w = h->d_modw_rm + off;
         st.bias = h->d_modb + (size_t)l * h->H;
-        st.a = l == 0 ? nullptr : mods_dev + (size_t)(l - 1) * B * h->H;
-        st.b = z_dev;
+        st.a = l == 0 ? nullptr : (const void*)(hid + (size_t)(l - 1) * B * h->H);
+        st.a_gran = 1;
+        st.b = z_gran ? (const void*)z_gran : (const void*)z_dev;
+        st.b_gran = z_gran ? 1 : 0;
+        st.b_lds = 1;
         st.out = mods_dev + (size_t)l * B * h->H;
+        st.gout = l + 1 < h->L ? (void*)(hid + (size_t)l * B * h->H) : nullptr;  // the last layer's readers are in the next launch
         st.H = h->H;
         st.Ka = Kh;
         st.Kb = h->Z;
@@ -1009,29 +1034,26 @@ int launch_chain(msiren_ctx* h, msiren::ChainParams& cp, int64_t B) {
     cp.B = (int)B;
     const int groups = (int)((B + 15) / 16);
     cp.gpc = (groups + h->chain_clusters - 1) / h->chain_clusters;
-    cp.ctr = h->d_chain_ctr;
     cp.count = h->plan;
     cp.gave_up = h->status_dev + 1;
-    cp.spin_limit = h->chain_spin;  // polls (s_sleep + one L2 round trip each): a few tenths of a second
-    for (int s = 0; s < cp.nstages; ++s) cp.base[s] = h->chain_base[s];
-    hipLaunchKernelGGL(msiren::modulator_chain_kernel, dim3((unsigned)(h->chain_clusters * msiren::CHAIN_MEMBERS)), dim3(256), 0,
-                       h->sc[h->cur].s, cp);
+    cp.spin_limit = h->chain_spin;  // sweeps (one round trip each): a few tenths of a second
+    cp.stamps = h->chain_stamps;
+    do cp.epoch = ++g_chain_epoch;
+    while (cp.epoch == 0);
+    hipLaunchKernelGGL(msiren::modulator_chain_kernel, dim3((unsigned)(h->chain_clusters * msiren::CHAIN_MEMBERS)), dim3(256),
+                       chain_lds_bytes(h), h->sc[h->cur].s, cp);
     HIPCHK(hipGetLastError());
-    // every cluster's active members add 1 per stage, whether or not the cluster has rows
-    for (int s = 0; s < cp.nstages; ++s) h->chain_base[s] += (unsigned)std::min(cp.st[s].H / 16, msiren::CHAIN_MEMBERS);
     return 0;
 }
 
 // a chain launch gave up a wait (the flag is raised by the kernel): its outputs and everything computed from them are
-// not valid.  Counters back to zero, chain off for this handle -- the per-layer launches take over.
+// not valid.  Chain off for this handle -- the per-layer launches take over.
 bool take_chain_flag(msiren_ctx* h) {
     if (!h->status_host || !h->status_host[1]) return false;
     h->status_host[1] = 0;
     h->chain_events++;
     h->chain_on = 0;
     h->chain_rerun_pending = true;
-    (void)hipMemset(h->d_chain_ctr, 0, (size_t)h->chain_clusters * msiren::CHAIN_STAGES * sizeof(unsigned));
-    for (auto& b : h->chain_base) b = 0;
     return true;
 }
 
@@ -1040,7 +1062,10 @@ int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_d
     if (!h->have_modulator) return fail(MSIREN_E_STATE, "modulator.* weights were not loaded");
     if (use_chain(h, B)) {
         msiren::ChainParams cp{};
-        chain_add_modulator_stages(h, cp, z_dev, B, mods_dev);
+        unsigned long long *g_a3, *g_z, *g_hid;
+        int rc = chain_exchange(h, B, &g_a3, &g_z, &g_hid);
+        if (rc) return rc;
+        chain_add_modulator_stages(h, cp, z_dev, nullptr, g_hid, B, mods_dev);  // the latent is there before the launch: plain
         return launch_chain(h, cp, B);
     }
     size_t off = 0;
@@ -1150,23 +1175,29 @@ int launch_encoder_modulator(msiren_ctx* h, const float* tiles_dev, int64_t B, f
     hipLaunchKernelGGL(msiren::encoder_conv_kernel, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, feat);
     HIPCHK(hipGetLastError());
     msiren::ChainParams cp{};
+    unsigned long long *g_a3, *g_z, *g_hid;
+    rc = chain_exchange(h, B, &g_a3, &g_z, &g_hid);
+    if (rc) return rc;
     msiren::ChainStage& c3 = cp.st[cp.nstages++];
     c3.w = h->d_c3w_rm;
     c3.bias = h->enc.c3b;
     c3.b = feat;
     c3.out = a3;
+    c3.gout = g_a3;
     c3.H = 64;
     c3.Kb = 2048;
     c3.act = msiren::LIN_ACT_LEAKY02;
     msiren::ChainStage& fc = cp.st[cp.nstages++];
     fc.w = h->d_fcw_rm;
     fc.bias = h->enc.fcb;
-    fc.b = a3;
+    fc.b = g_a3;
+    fc.b_gran = 1;
     fc.out = z_dev;
+    fc.gout = g_z;
     fc.H = h->Z;
     fc.Kb = 64;
     fc.act = msiren::LIN_ACT_NONE;
-    chain_add_modulator_stages(h, cp, z_dev, B, mods_dev);
+    chain_add_modulator_stages(h, cp, z_dev, g_z, g_hid, B, mods_dev);
     return launch_chain(h, cp, B);
 }
 
@@ -1404,11 +1435,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
         h->status_host[0] = h->status_host[1] = 0;  // [0] f16x3 domain guard, [1] modulator chain gave up a wait
         e = hipHostGetDevicePointer((void**)&h->status_dev, (void*)h->status_host, 0);
     }
-    if (e == hipSuccess && h->chain_clusters > 0) {
-        const size_t nb = (size_t)h->chain_clusters * msiren::CHAIN_STAGES * sizeof(unsigned);
-        e = hipMalloc((void**)&h->d_chain_ctr, nb);
-        if (e == hipSuccess) e = hipMemset(h->d_chain_ctr, 0, nb);
-    }
+
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -1426,7 +1453,6 @@ int msiren_destroy(msiren_handle h) {
         if (c.s) (void)hipStreamSynchronize(c.s);
     if (h->comm) (void)msiren_comm_destroy(h);
     if (h->status_host) (void)hipHostFree((void*)h->status_host);
-    if (h->d_chain_ctr) (void)hipFree(h->d_chain_ctr);
     if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
     if (h->d_wp16) (void)hipFree(h->d_wp16);
     if (h->d_wp16n) (void)hipFree(h->d_wp16n);
@@ -1437,7 +1463,7 @@ int msiren_destroy(msiren_handle h) {
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
                       &h->sc[0].patches, &h->sc[0].keep, &h->sc[0].rec, &h->sc[1].mods, &h->sc[1].modpad, &h->sc[1].latent,
-                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec, &h->sc[0].queue, &h->sc[1].queue, &h->sc[0].feat, &h->sc[1].feat, &h->sc[0].plan, &h->sc[1].plan};
+                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec, &h->sc[0].queue, &h->sc[1].queue, &h->sc[0].feat, &h->sc[1].feat, &h->sc[0].plan, &h->sc[1].plan, &h->sc[0].gran, &h->sc[1].gran};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& pr : h->prof_events) {
@@ -2140,9 +2166,31 @@ int msiren_comm_destroy(msiren_handle h) {
     return 0;
 }
 
+int msiren_chain_timeline(msiren_handle h, const float* tiles_dev, int64_t B, float* out_dev, uint64_t* stamps_host) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (B <= 0 || !tiles_dev || !out_dev || !stamps_host) return fail(MSIREN_E_INVALID, "bad arguments");
+    if (!use_chain(h, B)) return fail(MSIREN_E_INVALID, "chain timeline: the handle does not use the modulator chain (two streams, MSIREN_CHAIN=0, shape)");
+    const size_t nst = (size_t)h->chain_clusters * msiren::CHAIN_MEMBERS * (msiren::CHAIN_STAGES + 1) * sizeof(uint64_t);
+    DevBuf st;
+    if ((rc = ensure(h, st, nst))) return rc;
+    hipStream_t s = h->sc[h->cur].s;
+    HIPCHK(hipMemsetAsync(st.p, 0, nst, s));
+    h->chain_stamps = (unsigned long long*)st.p;
+    rc = forward_tiles_dev(h, tiles_dev, B, out_dev);
+    h->chain_stamps = nullptr;
+    if (!rc) {
+        HIPCHK(hipMemcpyAsync(stamps_host, st.p, nst, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    (void)hipStreamSynchronize(s);
+    HIPCHK(hipFree(st.p));
+    return rc;
+}
+
 int msiren_chain_info(msiren_handle h, int32_t* active, int64_t* events) {
     if (!h || !active || !events) return fail(MSIREN_E_INVALID, "null argument");
-    *active = (h->chain_on && h->d_chain_ctr && h->chain_clusters > 0 && h->nstreams == 1) ? 1 : 0;
+    *active = (h->chain_on && h->chain_clusters > 0 && h->nstreams == 1) ? 1 : 0;
     *events = h->chain_events;
     return 0;
 }
