@@ -17,6 +17,8 @@ Arrays: numpy float32 in -> numpy out; a ``DeviceArray`` (``model.device_array``
 crosses PCIe.  ``metrics_error`` keeps everything between its steps on the device: tiles are uploaded once, the
 reconstruction and the folded fully-sampled image come back once, for the host-side metrics (mri_inr_amd/metrics.py).
 
+``visual_error`` (src/util/error.py:104-183) is the same chain for ONE slice with images written instead of scores.
+
 ``metrics_error`` does what the reference does, in its order: black-tile filter -> model on the kept tiles -> zeros
 re-inserted -> weighted overlap-add of the 24x24 outputs; the fully-sampled tiles folded with the plain overlap
 average give the image the reconstruction is scored against (error.py:251-254) -- not the raw slice: on sizes that
@@ -130,3 +132,41 @@ def metrics_error(model, fully_sampled, undersampled, img_information, device, o
     rec = reconstruct_from_patches(model, d_under, img_information).numpy()[0]
     full = patches_to_image(d_full, img_information, outer_patch_size, inner_patch_size, model=model).numpy()[0]
     return calculate_psnr(full, rec), calculate_ssim(full, rec), calculate_nrmse(full, rec)
+
+
+def _unit_range(a):
+    lo, hi = float(a.min()), float(a.max())
+    return (a - lo) / (hi - lo) if hi > lo else np.zeros_like(a)
+
+
+def visual_error(model, output_dir, filename, fully_sampled, undersampled, img_information, device, outer_patch_size,
+                 inner_patch_size, siren_patch_size):
+    """The reconstruction of one slice next to what it came from, as images.  error.py:104-183: black-tile filter ->
+    model -> zeros re-inserted -> weighted fold; the undersampled and fully-sampled tiles folded with the plain overlap
+    average; then ``{filename}_reconstructed / _undersampled / _fully_sampled / _difference / _comparison`` under
+    ``output_dir``.  Every array is written as ``.npy`` (what a test can check) and, where matplotlib is importable, as
+    ``.png`` (min-max scaled; the difference |fully - reconstructed| in viridis, as the reference)."""
+    import os
+
+    if siren_patch_size != model.siren_patch_size:
+        raise ValueError(f"siren_patch_size {siren_patch_size} differs from the model's {model.siren_patch_size}")
+    bind(model)
+    d_under, _ = _to_device(model, undersampled, 3)
+    d_full, _ = _to_device(model, fully_sampled, 3)
+    rec = reconstruct_from_patches(model, d_under, img_information).numpy()[0]
+    under = patches_to_image(d_under, img_information, outer_patch_size, inner_patch_size, model=model).numpy()[0]
+    full = patches_to_image(d_full, img_information, outer_patch_size, inner_patch_size, model=model).numpy()[0]
+    images = {"reconstructed": rec, "undersampled": under, "fully_sampled": full, "difference": np.abs(full - rec)}
+    os.makedirs(output_dir, exist_ok=True)
+    for kind, a in images.items():
+        np.save(os.path.join(output_dir, f"{filename}_{kind}.npy"), a)
+    try:
+        from matplotlib import image as mpl_image
+    except ImportError:
+        return images
+    for kind, a in images.items():
+        mpl_image.imsave(os.path.join(output_dir, f"{filename}_{kind}.png"), _unit_range(a),
+                         cmap="viridis" if kind == "difference" else "gray", vmin=0.0, vmax=1.0)
+    side_by_side = np.concatenate([_unit_range(images[k]) for k in ("undersampled", "fully_sampled", "reconstructed", "difference")], axis=1)
+    mpl_image.imsave(os.path.join(output_dir, f"{filename}_comparison.png"), side_by_side, cmap="gray", vmin=0.0, vmax=1.0)
+    return images

@@ -13,7 +13,9 @@ load ``config.testing.model_path``, reconstruct ``config.data.metric_samples`` s
   * ``data.dataset: synthetic`` / ``testing.model_path: synthetic`` select seeded synthetic slices and
     weights (no fastMRI data or checkpoints here); a directory of ``*.npy`` slice pairs
     (``<name>_fully.npy`` / ``<name>_under.npy``) is read otherwise;
-  * plots (seaborn/matplotlib box and density plots) are not produced.
+  * ``data.visual_samples`` slices get the reference's per-slice image folder (:122-173; ``harness.visual_error``: arrays as
+    ``.npy``, images as ``.png`` without the reference's colour bars); the seaborn box and density plots of the metric
+    samples are not produced.
 """
 
 from __future__ import annotations
@@ -30,7 +32,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from mri_inr_amd import ModulatedSiren, load_configuration, model_kwargs, synthetic  # noqa: E402
 from mri_inr_amd.configuration import parse_args  # noqa: E402
 from mri_inr_amd import harness  # noqa: E402
-from mri_inr_amd.harness import image_to_patches, metrics_error  # noqa: E402
+from mri_inr_amd.harness import image_to_patches, metrics_error, visual_error  # noqa: E402
 from mri_inr_amd.weights import load_checkpoint  # noqa: E402
 
 
@@ -51,9 +53,9 @@ def save_metrics_summary(psnr_values, ssim_values, nrmse_values, output_dir):
             f.write("\n")
 
 
-def samples(config):
+def samples(config, n=None):
     """Yield (fully_sampled, undersampled, filename) float32 (H, W) pairs."""
-    n = config.data.metric_samples
+    n = config.data.metric_samples if n is None else n
     if config.data.dataset == "synthetic":
         for k in range(n or 8):
             full = synthetic.make_slice(k, brain_mask=True)
@@ -88,6 +90,15 @@ def test_mod_siren(config):
     names, psnrs, ssims, nrmses = [], [], [], []
     t_gpu = 0.0
     O, I, S = config.model.outer_patch_size, config.model.inner_patch_size, config.model.siren_patch_size
+    if config.data.visual_samples > 0:
+        print("Evaluating visual samples ...")
+        for i, (full, under, name) in enumerate(samples(config, config.data.visual_samples)):
+            print(f"Processing visual sample {i + 1}/{config.data.visual_samples}...")
+            fully_sampled_patch, _ = image_to_patches(model.device_array((1,) + full.shape).copy_from(full[None]), O, I)
+            undersampled_patch, undersampled_information = image_to_patches(
+                model.device_array((1,) + under.shape).copy_from(under[None]), O, I)
+            visual_error(model, os.path.join(output_dir, name), name, fully_sampled_patch, undersampled_patch,
+                         undersampled_information, "cuda", O, I, S)
     print("Evaluating metric samples ...")
     for i, (full, under, name) in enumerate(samples(config)):
         print(f"Processing metric sample {i + 1}...")

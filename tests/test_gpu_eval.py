@@ -22,7 +22,7 @@ YAML = """
 data:
   dataset: {data}
   metric_samples: 0
-  visual_samples: 0
+  visual_samples: 1
   acceleration: 6
   center_fraction: 0.05
 model:
@@ -99,6 +99,21 @@ def test_eval_driver_artefacts_and_scores(tmp_path):
             hh, ww = full.shape
             assert np.allclose(ref[:hh, :ww], full, atol=1e-6)
             assert ref.shape != full.shape
+
+    # data.visual_samples = 1: the first slice's image folder (reference test_mod_siren.py:122-173, error.py:104-183)
+    vis = out / "a_square"
+    full, under = pairs["a_square"]
+    rec = orc.reconstruct_slice(sd, under, num_layers=5, dtype=np.float64)
+    got_rec = np.load(vis / "a_square_reconstructed.npy")
+    assert got_rec.shape == rec.shape and np.abs(got_rec - rec).max() <= 1e-4 * np.abs(rec).max()
+    t_u, info = orc.image_to_patches(under, 32, 16)
+    assert np.allclose(np.load(vis / "a_square_undersampled.npy"), orc.patches_to_image(t_u, info, 32, 16), atol=1e-6)
+    t_f, _ = orc.image_to_patches(full, 32, 16)
+    ref_full = orc.patches_to_image(t_f, info, 32, 16)
+    assert np.allclose(np.load(vis / "a_square_fully_sampled.npy"), ref_full, atol=1e-6)
+    assert np.allclose(np.load(vis / "a_square_difference.npy"), np.abs(ref_full - got_rec), atol=1e-6)
+    for kind in ("reconstructed", "undersampled", "fully_sampled", "difference", "comparison"):
+        assert (vis / f"a_square_{kind}.png").stat().st_size > 0
 
 
 def test_harness_mirror_matches_oracle_tiling():
