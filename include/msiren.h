@@ -277,8 +277,9 @@ MSIREN_API int msiren_abi_version(void);
  * s_memtime at the end of each of the 32 hidden-layer tiles.  (H=256, L=5, sine.) */
 MSIREN_API int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev,
                                      uint64_t* stamps_host);
-/* Same for the weight-stationary f16x3 trunk: per workgroup and slot (first 96), 4 uint64: s_memtime at the top of the
- * slot's bookkeeping, at the start and at the end of its MFMA body, and s_memrealtime at the end.  (H=256, sine.) */
+/* Same for the weight-stationary f16x3 trunk: per workgroup and slot (first 96), 8 uint64: [0..2] s_memtime at the top of the
+ * slot's bookkeeping, at the start and at the end of its MFMA body, [3] s_memrealtime at the end, [4..6] s_memtime inside the slot
+ * boundary (modulation rows staged / pass id handled / end).  (H=256, sine.) */
 MSIREN_API int msiren_f16x3w_timeline(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev,
                                       uint64_t* stamps_host);
 MSIREN_API int msiren_trunk_timeline(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev,

@@ -1969,7 +1969,7 @@ int msiren_f16x3w_timeline(msiren_handle h, const float* mods_dev, int64_t B, fl
     p.div_m = (unsigned)(((1ULL << p.div_k) + (unsigned)upp - 1) / (unsigned)upp);
     const int grid = (int)std::min<int64_t>(h->cus_limit, ((int64_t)p.total_units + 1) / 2);
     DevBuf st, q;
-    const size_t nst = (size_t)grid * 96 * 4 * sizeof(uint64_t);
+    const size_t nst = (size_t)grid * 96 * 8 * sizeof(uint64_t);
     if ((rc = ensure(h, st, nst)) || (rc = ensure(h, q, 256))) return rc;
     hipStream_t s = h->sc[h->cur].s;
     HIPCHK(hipMemsetAsync(st.p, 0, nst, s));

@@ -622,10 +622,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
 
     int dbg_slot = 0;
     (void)dbg_slot;
-    auto stamp = [&](int which) {  // diagnostic instance only: [workgroup][slot < 96][4] s_memtime (3: s_memrealtime)
+    auto stamp = [&](int which) {  // diagnostic instance only: [workgroup][slot < 96][8] s_memtime (3: s_memrealtime; 4..6: inside the slot boundary)
         if constexpr (DBG) {
             const unsigned long long t = which == 3 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
-            if (tid == 0 && dbg_slot < 96) p.stamps[((size_t)blockIdx.x * 96 + dbg_slot) * 4 + which] = t;
+            if (tid == 0 && dbg_slot < 96) p.stamps[((size_t)blockIdx.x * 96 + dbg_slot) * 8 + which] = t;
         }
     };
 
@@ -666,7 +666,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         }                                                                                                            \
         stamp(2);                                                                                                    \
         stamp(3);                                                                                                    \
-        if constexpr (DBG) ++dbg_slot;                                                                               \
         /* ---- slot boundary ---- */                                                                                \
         /* (the prev final slot's output was finished in this slot's region 7) */                                   \
         if (pv_final && pv_out) fin_par ^= 1;                                                                        \
@@ -679,6 +678,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
             r0n = r0n >= NR ? r0n - NR : r0n;                                                                        \
             mods_store(b, r0n, mnext);                                                                               \
         }                                                                                                            \
+        stamp(4);                                                                                                    \
         /* pass-id pipeline: the atomic is issued at the pass boundary, its result written to LDS one slot later (no */ \
         /* wait on the way), read by everybody another slot later (a barrier in between); needed from the final layer on */ \
         if (k_in_pass == 0) { /* the atomic was issued a whole slot ago; the body since was a final one (a pass's first */ \
@@ -691,6 +691,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
             if ((unsigned)id < npasses) pass_units(id, u0_nxt, nb_nxt);                                              \
             else nb_nxt = 0;                                                                                         \
         }                                                                                                            \
+        stamp(5);                                                                                                    \
         ++k_in_pass;                                                                                                 \
         /* this slot becomes the prev one */                                                                         \
         pv_final = l == L - 1;                                                                                       \
@@ -708,6 +709,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
             l0_row = r0n >= NR ? r0n - NR : r0n;                                                                     \
         }                                                                                                            \
         slot_par ^= 1;                                                                                               \
+        stamp(6);                                                                                                    \
+        if constexpr (DBG) ++dbg_slot;                                                                               \
     } while (0)
 
     for (;;) {  // passes

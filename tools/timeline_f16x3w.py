@@ -17,7 +17,7 @@ mods = syn.make_mods(1, 5, B, 256)
 d_m = m.device_array(mods.shape).copy_from(mods)
 d_o = m.device_array((B, 24, 24))
 grid = min(256, (B * 18 + 1) // 2)
-st = np.zeros((grid, 96, 4), dtype=np.uint64)
+st = np.zeros((grid, 96, 8), dtype=np.uint64)
 for _ in range(3):
     _lib.check(m._lib.msiren_f16x3w_timeline(m._h, d_m.ptr, B, d_o.ptr, st.ctypes.data))
 t = st.astype(np.int64)
@@ -28,9 +28,10 @@ body = (t[:, :, 2] - t[:, :, 1])
 gap = np.zeros_like(book)
 gap[:, 1:] = t[:, 1:, 0] - t[:, :-1, 2]
 n = min(96, int(valid.sum(1).min()))
-print("slot  bookkeeping  body  boundary-before   (median cycles over workgroups; MFMA floor of a body: 3072)")
+print("slot  bookkeeping  body  boundary-before | this slot's boundary: mods staged, pass id, rest   (median cycles over workgroups; MFMA floor of a body: 3072)")
 for i in range(min(n, 40)):
-    print(f"{i:3d} {int(np.median(book[:, i])):8d} {int(np.median(body[:, i])):8d} {int(np.median(gap[:, i])):8d}")
+    b1, b2, b3 = (int(np.median(t[:, i, 4] - t[:, i, 2])), int(np.median(t[:, i, 5] - t[:, i, 4])), int(np.median(t[:, i, 6] - t[:, i, 5])))
+    print(f"{i:3d} {int(np.median(book[:, i])):8d} {int(np.median(body[:, i])):8d} {int(np.median(gap[:, i])):8d} | {b1:6d} {b2:6d} {b3:6d}")
 per = np.median(t[:, 17:33, 2] - t[:, 16:32, 2], axis=0)
 print("slot period (slots 17..32):", [int(x) for x in per])
 dm = t[:, n - 1, 2] - t[:, 16, 2]
