@@ -571,6 +571,23 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
 
     // One k-step region of a slot.  VAR: 0 = normal epilogue, 1 = final-layer epilogue + layer 0.  FL: 0 = a layer's first
     // unit (waits for the fragments fetched during the slot before), 1 = middle, 2 = last (fetches the next layer's).
+// B fragment J (hi g0, lo g0, hi g1, lo g1) of the NEXT k-step (S == 7: of the next slot's first), one per gap of the
+// generated schedule, fenced so that the compiler leaves it in its gap (it would bunch the four at the region's start, or
+// sink them to their first use).  Same bits, same-box A/B (profiles/r3/13_ab_spread_reads.txt): 0.2723-0.2753 ms against
+// 0.2717-0.2722 ms with the four in a bunch at the region's start -- no gain, so the bunch stays the default
+// (-DMSIREN_WS_SPREAD_READS=1 builds the spread form).
+#ifndef MSIREN_WS_SPREAD_READS
+#define MSIREN_WS_SPREAD_READS 0
+#endif
+#define MSIREN_WS_BREAD(S, J)                                                                                        \
+    do {                                                                                                             \
+        if (MSIREN_WS_SPREAD_READS && (!(MSIREN_WS_ABL & 2) || (S) == 7)) {                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            Bf[((S) + 1) & 1][J] = lds_frag(((S) < 7 ? cimg_ + ((S) + 1) * 4096 : nimg_) + (J) * 1024);              \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+    } while (0)
+
 #define MSIREN_WS_REGION(PAR, VAR, FL, S)                                                                            \
     do {                                                                                                             \
         constexpr int PP_ = (PAR) ^ 1;                                                                               \
@@ -582,7 +599,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
             __builtin_amdgcn_s_barrier();                                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
-        if (!(MSIREN_WS_ABL & 2) || (S) == 7) {   /* B fragments of the next k-step (S == 7: the next slot's first, its bias and its first tables) */      \
+        if (!MSIREN_WS_SPREAD_READS && (!(MSIREN_WS_ABL & 2) || (S) == 7)) {   /* B fragments of the next k-step, in a bunch (A/B build) */ \
             const unsigned char* src_ = (S) < 7 ? cimg_ + ((S) + 1) * 4096 : nimg_;                                  \
             Bf[((S) + 1) & 1][0] = lds_frag(src_ + 0);                                                               \
             Bf[((S) + 1) & 1][1] = lds_frag(src_ + 1024);                                                            \

@@ -85,6 +85,29 @@ for u, g in ((0, 0), (0, 1), (1, 0), (1, 1)):   # layer 0 of the next pass: hi h
     put(B, j + 16, f"MSIREN_WS_STORE_PIECE(l0h_, l0l_, {u}, {g})")
     j += 17
 
+# ---- B fragments of the next k-step: one ds_read_b128 per gap instead of four in a bunch at the region's start ----
+# (four waves issue them at the same moment behind the slot's barrier; bunched, the LDS queue held every wave's MFMA stream
+# for ~50 cycles per region.)  Order of need in the next region: hi g0 (MFMA 0), hi g1 (MFMA 1), lo g0 (8), lo g1 (9).
+# Gaps with an even MFMA index (odd ones carry a loading slot's weight loads), free of epilogue work where the table has
+# such gaps, else beside a plain (4-cycle) statement -- never beside a sine.
+SPREAD = "--bunched" not in sys.argv
+
+
+def place_reads(tab):
+    for s in range(8):
+        cand = [24 * s + i for i in (2, 4, 6, 8, 10, 12, 14, 16)]
+        free = [g for g in cand if g not in tab]
+        plain = [g for g in cand if g in tab and not any(("_S0(" in st or "_S1(" in st or "RED" in st or "STORE" in st or "WAIT" in st or "FIN" in st) for st in tab[g])]
+        chosen = sorted((free + plain)[:4])
+        assert len(chosen) == 4, (s, free, plain)
+        for g, frag in zip(chosen, (0, 2, 1, 3)):
+            tab.setdefault(g, []).append(f"MSIREN_WS_BREAD({s}, {frag})")
+
+
+if SPREAD:
+    place_reads(A)
+    place_reads(B)
+
 # region 7 of a final slot (behind the barrier): finish the prev final slot's output
 put(B, 168, "MSIREN_WS_FIN0()", True); put(B, 174, "MSIREN_WS_FIN1()", True); put(B, 176, "MSIREN_WS_FIN2()", True); put(B, 178, "MSIREN_WS_FIN3()", True)
 
