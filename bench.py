@@ -43,7 +43,6 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-SUSTAINED_F16_MFMA_TFLOPS = 1476.0
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak (= vector peak)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (no sparsity)
 MIN_WARMUP_S = 0.4             # untimed: the card needs a few hundred ms under load before its clock settles
@@ -398,6 +397,13 @@ def main():
         _lib.check(lib.msiren_profile_enable(h, 0))
         _lib.check(lib.msiren_set_streams(h, args.streams))
 
+    # behind the timed region and the roofline phase (the card is warm): the power-limited MFMA ceiling of this card
+    sustained_tflops = sustained_mhz = None
+    if rank == 0 and not args.no_extras:
+        t_, m_ = C.c_double(), C.c_double()
+        _lib.check(lib.msiren_mfma_sustained_probe(h, C.byref(t_), C.byref(m_)))
+        sustained_tflops, sustained_mhz = t_.value, m_.value
+
     px_per_step = n_total * 320 * 320
     value = px_per_step * args.steps / elapsed / 1e6
     # the slice pipeline skips black tiles (mean < 1e-10, tiling.py:184-198): only evaluated tiles count as work
@@ -473,9 +479,12 @@ def main():
             "hbm_peak_gb_s": 8000.0,
             "flops_per_launch": flops_launch, "avg_launch_ms": trunk_avg_s * 1e3, "launches": int(launches.value),
             "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-            # tools/mfma_peak_probe.hip: all 256 CUs issuing only fp16 MFMAs sustain 1476 TFLOP/s under the
-            # board power limit (profiles/r1/10_*); context for `frac`, which is against the nominal peak
-            "sustained_fp16_mfma_tflops_measured": SUSTAINED_F16_MFMA_TFLOPS,
+            # what this card sustains on nothing but the f16x3 trunk's MFMA stream with operands of the trunk's magnitudes,
+            # measured in this run behind the timed region (msiren_mfma_sustained_probe; round 1's standalone probe gave
+            # 1476 TFLOP/s): the power-limited ceiling -- context for `frac`, which is against the NOMINAL peak
+            "sustained_fp16_mfma_tflops_measured": sustained_tflops,
+            "sustained_mfma_clock_mhz_equivalent": sustained_mhz,
+            "frac_of_sustained_mfma_rate": (achieved / (sustained_tflops / 3.0)) if (sustained_tflops and dtype == "f16x3") else None,
             "measured": ("HIP event pairs on the kernel's stream; single-stream phase of this run (kernel alone: what a handle with "
                          "one stream launches), rank 0; the two-stream timed region launches " + kernel_two_streams +
                          " (roofline_timed_mode)") if args.streams > 1 else

@@ -263,6 +263,12 @@ MSIREN_API int msiren_range_events(msiren_handle h, int64_t* count);
  * MSIREN_E_HIP (outputs since the previous sync are not valid).  Either way the handle uses one launch per layer from
  * then on.  *active: 1 while the handle would use the single launch; *events: launches that gave up, since msiren_create. */
 MSIREN_API int msiren_chain_info(msiren_handle h, int32_t* active, int64_t* events);
+/* Diagnostic: the rate the device sustains on nothing but the split-fp16 trunk's MFMA stream (v_mfma_f32_16x16x32_f16, one wave
+ * per SIMD on every CU, the trunk's three products per k-step on operands of the trunk's magnitudes), ~10 ms.  *tflops: fp16
+ * MFMA TFLOP/s issued chip-wide (divide by 3 for the algorithmic figure of the f16x3 roofline); *mhz_equivalent (optional):
+ * the clock at which one MFMA per 16 cycles and SIMD gives that rate.  What the nominal peak becomes under the power limit
+ * on real data; bench.py reports it beside the roofline, never as `peak`. */
+MSIREN_API int msiren_mfma_sustained_probe(msiren_handle h, double* tflops, double* mhz_equivalent);
 /* Diagnostic: one msiren_forward_tiles_dev whose chain launch is stamped.  stamps_host: (clusters x 16 workgroups) x 17 uint64,
  * clusters = min(16, CUs / 16): [0] s_memrealtime (100 MHz) at the workgroup's start, [1 + s] after its stage s (0 = not run). */
 MSIREN_API int msiren_chain_timeline(msiren_handle h, const float* tiles_dev, int64_t B, float* out_dev, uint64_t* stamps_host);

@@ -92,6 +92,7 @@ PROTOTYPES = {
     "msiren_range_events": (C.c_int, [_vp, C.POINTER(_i64)]),
     "msiren_chain_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(_i64)]),
     "msiren_chain_timeline": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "msiren_mfma_sustained_probe": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "msiren_comm_unique_id": (C.c_int, [_vp, C.c_size_t]),
     "msiren_comm_init_rank": (C.c_int, [_vp, _vp, C.c_size_t, _i32, _i32]),
     "msiren_comm_init_all": (C.c_int, [C.POINTER(_vp), _i32]),

@@ -23,6 +23,7 @@
 #include "../../include/msiren.h"
 #include "encoder_modulator.hip.h"
 #include "modulator_chain.hip.h"
+#include "mfma_probe.hip.h"
 #include "pass_queue.h"
 #include "weights_blob.h"
 #include "siren_trunk_f16x3.hip.h"
@@ -2163,6 +2164,48 @@ int msiren_comm_destroy(msiren_handle h) {
     h->comm = nullptr;
     h->comm_n = 1;
     h->comm_rank = 0;
+    return 0;
+}
+
+int msiren_mfma_sustained_probe(msiren_handle h, double* tflops, double* mhz_equivalent) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (!tflops) return fail(MSIREN_E_INVALID, "null argument");
+    // operands with the trunk's magnitudes: weights 0.1 rms (hi) and 2^-11 of that (lo); activations in [-1.5, 1.5] and 2^-11 of that
+    const size_t n = (size_t)8 * 12 * 512;
+    std::vector<_Float16> host(n);
+    unsigned st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (float)((st >> 8) & 0xffff) / 32768.f - 1.f; };  // [-1, 1)
+    for (size_t g = 0; g < 8; ++g)
+        for (int kind = 0; kind < 12; ++kind)
+            for (int e = 0; e < 512; ++e) {
+                const float u = rnd();
+                float v;
+                if (kind < 4) v = 0.17f * u;                       // W hi
+                else if (kind < 8) v = 0.17f * u * (1.f / 2048.f);  // W lo
+                else if (kind < 10) v = 1.5f * u;                   // x hi
+                else v = 1.5f * u * (1.f / 2048.f);                 // x lo
+                host[(g * 12 + kind) * 512 + e] = (_Float16)v;
+            }
+    DevBuf src, sink;
+    if ((rc = ensure(h, src, n * sizeof(_Float16))) || (rc = ensure(h, sink, 1024))) return rc;
+    hipStream_t s = h->sc[h->cur].s;
+    HIPCHK(hipMemcpyAsync(src.p, host.data(), n * sizeof(_Float16), hipMemcpyHostToDevice, s));
+    const int iters = 40000;  // x 24 MFMAs x 16 cycles = 15.4 M cycles: ~8 ms, long enough for the clock to settle
+    const int grid = h->num_cus;
+    hipLaunchKernelGGL(msiren::mfma_sustained_probe_kernel, dim3(grid), dim3(256), 0, s, (const _Float16*)src.p, (float*)sink.p, iters / 8);  // warm
+    HIPCHK(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(msiren::mfma_sustained_probe_kernel, dim3(grid), dim3(256), 0, s, (const _Float16*)src.p, (float*)sink.p, iters);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, s));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    const double flops = (double)grid * 4 * (double)iters * 24 * (16.0 * 16 * 32 * 2);
+    *tflops = flops / (ms * 1e-3) * 1e-12;
+    if (mhz_equivalent) *mhz_equivalent = (double)iters * 24 * 16.0 / (ms * 1e-3) * 1e-6;  // the clock at which one MFMA per 16 cycles gives this rate
+    (void)hipFree(src.p);
+    (void)hipFree(sink.p);
     return 0;
 }
 

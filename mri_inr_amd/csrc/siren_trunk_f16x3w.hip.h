@@ -213,6 +213,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
 // can touch them.  As C++ values they were a loop-carried 64-register phi web over the twelve slot bodies: 16 v_mov_b64 of
 // reconciliation at the end of every body; pinned with register constraints: 231 spills.
 #define MSIREN_WS_V(PAR, T, G) (192 + 32 * (PAR) + 8 * (T) + 4 * (G))
+#if defined(MSIREN_WS_ABL) && (MSIREN_WS_ABL & 8)  /* ablation (timing only): no MFMAs at all -- what is left of a slot is its control flow */
+#define MSIREN_WS_MFMA(PAR, T, G, S, HL, B) asm volatile("" : : "v"(B))
+#define MSIREN_WS_MFMA0(PAR, T, G, S, HL, B, C) asm volatile("" : : "v"(B), "v"(C))
+#else
 #define MSIREN_WS_MFMA(PAR, T, G, S, HL, B)                                                                            \
     asm volatile("v_mfma_f32_16x16x32_f16 v[%1:%2], a[%3:%4], %0, v[%1:%2]"                                            \
                  : : "v"(B), "n"(MSIREN_WS_V(PAR, T, G)), "n"(MSIREN_WS_V(PAR, T, G) + 3), "n"(MSIREN_WS_A(S, T, HL)), \
@@ -221,6 +225,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     asm volatile("v_mfma_f32_16x16x32_f16 v[%2:%3], a[%4:%5], %0, %1"                                                  \
                  : : "v"(B), "v"(C), "n"(MSIREN_WS_V(PAR, T, G)), "n"(MSIREN_WS_V(PAR, T, G) + 3),                     \
                    "n"(MSIREN_WS_A(S, T, HL)), "n"(MSIREN_WS_A(S, T, HL) + 3))
+#endif
 
     // Keeping the register allocator OUT of the accumulator file: under pressure it splits arch-VGPR values into AGPRs
     // (v_accvgpr_write / _read), i.e. over the fragments (seen: a pointer parked in a0..a3, then a fault).  a[192:255] are
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         if (q < 2) redW[(fin_par * 32 + q * 16 + n16) * 4 + wave] = q == 0 ? pa_[0] + pb_[0] : pa_[1] + pb_[1];      \
         part[0] = 0.f; part[1] = 0.f;                                                                                \
     } while (0)
-// Ablation builds (timing only, results wrong; never shipped): -DMSIREN_WS_ABL=bitmask
+// Ablation builds (timing only, results wrong; never shipped): -DMSIREN_WS_ABL=bitmask (8: no MFMAs, see MSIREN_WS_MFMA)
 //   1 = no epilogue in the gaps, 2 = no B-fragment LDS reads, 4 = no barrier
 #ifndef MSIREN_WS_ABL
 #define MSIREN_WS_ABL 0
