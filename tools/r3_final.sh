@@ -27,13 +27,16 @@ g++ -std=c++17 -O1 -fPIC -shared -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include test
 rm -f $out/librccl_stub.so $out/stub-*
 MSIREN_BENCH_BACKEND=gloo run bench_strong64_gloo4_one_card --gpus 4 --total-slices 64 --steps 10 --warmup 3 --no-cpu-baseline 
 python3 tools/latency.py > $out/latency.txt 2>&1
+# the opt-in one-launch modulator chain, same box: latency and the single-stream line
+MSIREN_CHAIN=1 python3 tools/latency.py > $out/latency_chain.txt 2>&1
+MSIREN_CHAIN=1 run bench_streams1_chain --streams 1 --no-cpu-baseline --no-extras
 python3 - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/r3/final/*.json')):
     try:
         d=json.loads([l for l in open(f).read().strip().splitlines() if l.startswith('{')][-1])
         r=d['roofline']; t=d.get('roofline_timed_mode',{})
-        print(f.split('/')[-1], d['n_gpus'], d['scaling'], round(d['value'],1), 'Mpx/s', round(d['ms_per_step'],4),'ms', r['kernel'], round(r['achieved'],1),'TF', round(r['frac'],3), 'timed', round(t.get('frac',0),3), d.get('check_nerr_vs_fp64_oracle'), d.get('extra'), d.get('collective_fallback'), d['config'].get('rccl_ranks'))
+        print(f.split('/')[-1], d['n_gpus'], d['scaling'], round(d['value'],1), 'Mpx/s', round(d['ms_per_step'],4),'ms', r['kernel'], round(r['achieved'],1),'TF', round(r['frac'],3), 'sustained', r.get('sustained_fp16_mfma_tflops_measured') and round(r['sustained_fp16_mfma_tflops_measured']), 'timed', round(t.get('frac',0),3), d.get('check_nerr_vs_fp64_oracle'), d.get('extra'), d.get('collective_fallback'), d['config'].get('rccl_ranks'))
     except Exception as e: print(f, 'ERR', e)
 PY
-cat $out/latency.txt | tail -4
+cat $out/latency.txt | tail -4; cat $out/latency_chain.txt | tail -3
