@@ -824,6 +824,9 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     // R = 3 leaves ~35 KB of LDS per CU free, enough for an encoder / modulator workgroup of the NEXT
     // call (other stream) to run beside the persistent trunk workgroup; R = 4 fills the CU.
     int ring = (h->nstreams > 1 || h->overlap) ? 3 : 4;
+    // depths other than 5 run the loop form of the kernel: with a ring of 3 hipcc gives it all 512 registers (and 188 bytes of
+    // scratch per lane), so nothing could run beside it anyway -- the ring of 4 has neither (164 + 240 registers)
+    if (ring == 3 && h->L != 5) ring = 4;
     if (h->ring_force) ring = h->ring_force;
     const bool r4 = ring >= 4 && msiren::F16Lds<4>::total(h->L) <= 160 * 1024;
     const int cus = h->cus_limit;

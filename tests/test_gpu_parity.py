@@ -327,6 +327,31 @@ def test_f16x3_full_forward_matches_fp32_path():
     assert nerr(b, a) < 5e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [3, 4, 6])
+def test_two_streams_at_other_depths_same_bits_as_one_stream(L):
+    """Depths other than 5 run the loop form of the register-resident trunk in two-stream mode (with the ring of 4: the ring-of-3
+    instance of that form spills); one stream: the weight-stationary trunk (3..5) or the same loop form.  Same bits."""
+    from mri_inr_amd import _lib
+
+    sd = syn.make_state_dict(seed=5, num_layers=L, trained_like=True)
+    m = make_model(sd, L=L, precision="f16x3")
+    tiles = [np.random.default_rng(10 * L + s).random((60 + 97 * s, 32, 32), dtype=np.float32) for s in range(4)]
+    d_in = [m.device_array(t.shape).copy_from(t) for t in tiles]
+    d_out = [m.device_array((t.shape[0], 24, 24)) for t in tiles]
+    for a, b, t in zip(d_in, d_out, tiles):
+        _lib.check(m._lib.msiren_forward_tiles_dev(m._h, a.ptr, t.shape[0], b.ptr))
+    m.sync()
+    one = [b.numpy() for b in d_out]
+    _lib.check(m._lib.msiren_set_streams(m._h, 2))
+    for _ in range(2):
+        for a, b, t in zip(d_in, d_out, tiles):
+            _lib.check(m._lib.msiren_forward_tiles_dev(m._h, a.ptr, t.shape[0], b.ptr))
+    m.sync()
+    for r, b in zip(one, d_out):
+        assert np.isfinite(r).all() and np.array_equal(r, b.numpy())
+
+
 def test_two_stream_pipelining_is_bit_identical():
     """msiren_set_streams(2): consecutive async calls alternate streams; results must not change."""
     from mri_inr_amd import _lib
