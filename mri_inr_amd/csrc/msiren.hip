@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>  // types only: librccl is dlopen'ed by the first msiren_comm_* call
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -76,6 +77,7 @@ struct msiren_ctx {
     } sc[2];
     int cur = 0, nstreams = 1;
     bool overlap = false;  // a host-pointer call is pipelining itself over both streams
+    bool solo = false;     // a synchronous host-pointer call is running on ONE stream: nothing of this handle is to run beside its trunk
     const int* plan = nullptr;  // device-side list of non-black patches in effect (slice pipeline only)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, std::vector<float>> tensors;  // state_dict, host copies
@@ -101,6 +103,8 @@ struct msiren_ctx {
     float* d_dump = nullptr;       // 256 floats: where lanes of the weight-stationary trunk that have nothing to store write
     // modulator chain (modulator_chain.hip.h): conv3, Linear(64, Z) and the Modulator layers in one launch, single-stream handles
     int chain_on = 0;              // MSIREN_CHAIN=1: on (read at create).  Off by default: measured no faster than a launch per layer
+    int trace_host = 0;            // MSIREN_TRACE_HOST=1: msiren_forward_tiles prints the host-side timeline of the call (stderr)
+    int host_first_pct = 50;       // MSIREN_HOST_SPLIT: share (percent) of the batch in the first of the two chunks of a host call
     int chain_clusters = 0;
     unsigned chain_spin = 400000;  // MSIREN_CHAIN_SPIN (tests: 0 = give up at the first poll that finds the stage unfinished)
     bool chain_rerun_pending = false;
@@ -791,7 +795,7 @@ int launch_trunk_f16x3w(msiren_ctx* h, const float* mods_dev, int64_t B, float* 
 // nothing can run beside it); with two streams the register-resident trunk wins because the next call's encoder and
 // modulator run beside it.  Depths 3..5 (its unit images + tables must fit the LDS); modulation buffer below 4 GB.
 bool use_f16x3w(msiren_ctx* h, int64_t B) {
-    return h->f16_ws && h->nstreams == 1 && !h->overlap && h->L >= 3 && h->L <= 8 &&
+    return h->f16_ws && (h->nstreams == 1 || h->solo) && !h->overlap && h->L >= 3 && h->L <= 8 &&
            msiren::WsLds<4>::total(h->L) <= 160 * 1024 && (int64_t)h->L * B * 256 * 4 < (1LL << 32);
 }
 
@@ -823,7 +827,7 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     if (units > 0x3fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     // R = 3 leaves ~35 KB of LDS per CU free, enough for an encoder / modulator workgroup of the NEXT
     // call (other stream) to run beside the persistent trunk workgroup; R = 4 fills the CU.
-    int ring = (h->nstreams > 1 || h->overlap) ? 3 : 4;
+    int ring = ((h->nstreams > 1 && !h->solo) || h->overlap) ? 3 : 4;
     // depths other than 5 run the loop form of the kernel: with a ring of 3 hipcc gives it all 512 registers (and 188 bytes of
     // scratch per lane), so nothing could run beside it anyway -- the ring of 4 has neither (164 + 240 registers)
     if (ring == 3 && h->L != 5) ring = 4;
@@ -1428,6 +1432,8 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_QUEUE_START")) h->queue_start = (unsigned)std::strtoul(e, nullptr, 0);
     if (const char* e = std::getenv("MSIREN_F16_WS")) h->f16_ws = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_CHAIN")) h->chain_on = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_TRACE_HOST")) h->trace_host = std::atoi(e);
+    if (const char* e = std::getenv("MSIREN_HOST_SPLIT")) h->host_first_pct = std::max(5, std::min(95, std::atoi(e)));
     if (const char* e = std::getenv("MSIREN_CHAIN_SPIN")) h->chain_spin = (unsigned)std::strtoul(e, nullptr, 0);
     h->chain_clusters = std::min(16, h->cus_limit / msiren::CHAIN_MEMBERS);  // at most one workgroup per CU: the whole grid is resident
     declare_expected(h);
@@ -1530,9 +1536,18 @@ int msiren_forward_mods_dev(msiren_handle h, const float* mods_dev, int64_t B, f
     return launch_trunk(h, mods_dev, B, out_dev);
 }
 
+namespace {
+struct SoloCall {  // marks a synchronous single-stream host call for its duration (trunk choice: use_f16x3w, ring depth)
+    msiren_ctx* h;
+    explicit SoloCall(msiren_ctx* hh, bool on = true) : h(hh) { if (h) h->solo = on; }
+    ~SoloCall() { if (h) h->solo = false; }
+};
+}  // namespace
+
 static int msiren_forward_mods_impl(msiren_handle h, const float* mods_host, int64_t B, float* out_host) {
     int rc = check(h);
     if (rc) return rc;
+    SoloCall solo(h);
     if (B < 0 || (B > 0 && (!mods_host || !out_host))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
     if (B == 0) return 0;
     const size_t nm = (size_t)h->L * B * h->H * sizeof(float), no = (size_t)B * h->P * sizeof(float);
@@ -1560,6 +1575,7 @@ int msiren_forward_latent_dev(msiren_handle h, const float* z_dev, int64_t B, fl
 static int msiren_forward_latent_impl(msiren_handle h, const float* z_host, int64_t B, float* out_host, float* mods_out_host) {
     int rc = check(h);
     if (rc) return rc;
+    SoloCall solo(h);
     if (B < 0 || (B > 0 && (!z_host || !out_host))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
     if (B == 0) return 0;
     const size_t nz = (size_t)B * h->Z * sizeof(float), no = (size_t)B * h->P * sizeof(float);
@@ -1595,36 +1611,59 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     if (B == 0) return 0;
     const size_t nt = (size_t)B * h->O * h->O * sizeof(float), no = (size_t)B * h->P * sizeof(float);
     if ((rc = ensure(h, h->ws_tiles, nt)) || (rc = ensure(h, h->ws_out, no))) return rc;
-    // A synchronous call cannot be overlapped by its caller, so a large one pipelines its copies itself: the
-    // batch is cut in two halves on the two streams -- the second half's upload runs beside the first half's
-    // kernels, the first half's download beside the second half's trunk.  (More than two chunks do not help:
-    // a pageable copy waits for its stream to drain.)  Patches are independent: the cut does not change results.
-    int nchunks = B >= 256 ? 2 : 1;
+    // One chunk on one stream (the weight-stationary trunk, alone on the chip) is the default.  MSIREN_HOST_CHUNKS=2 cuts the
+    // batch in two over the two streams -- the second part's upload runs beside the first part's kernels, the first part's
+    // download beside the second part's trunk -- which was the default while the register-resident trunk was the only one
+    // (round 2: 460 us per 400 tiles against 490 on one stream); with the weight-stationary trunk one chunk is as fast or
+    // faster (461-469 us against 469-481, same box, three handles each) and does not depend on where the two streams land
+    // (one handle in six ran the two-chunk form at 573 us).  (More than two chunks do not help: a pageable copy waits for
+    // its stream to drain.)  Patches are independent: the cut does not change results.
+    int nchunks = 1;
     if (h->host_chunks) nchunks = h->host_chunks;
     nchunks = (int)std::min<int64_t>(nchunks, B);
     const int cur0 = h->cur;
     const size_t tile_elems = (size_t)h->O * h->O;
+    // chunk boundaries: equal parts, except that two chunks may be cut unevenly (host_first_pct)
+    auto bound = [&](int k) -> int64_t {
+        if (nchunks == 2 && k == 1) return std::max<int64_t>(1, std::min<int64_t>(B - 1, B * h->host_first_pct / 100));
+        return B * k / nchunks;
+    };
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    auto us = [&]() { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
+    double tr[40];
+    int ntr = 0;
     h->overlap = nchunks > 1;
+    SoloCall solo(h, nchunks == 1);
     for (int k = 0; k < nchunks && !rc; ++k) {
-        const int64_t lo = B * k / nchunks, n = B * (k + 1) / nchunks - lo;
+        const int64_t lo = bound(k), n = bound(k + 1) - lo;
         h->cur = nchunks > 1 ? (k & 1) : cur0;
         float* d_t = (float*)h->ws_tiles.p + (size_t)lo * tile_elems;
         hipError_t e = hipMemcpyAsync(d_t, tiles_host + (size_t)lo * tile_elems, (size_t)n * tile_elems * sizeof(float),
                                       hipMemcpyHostToDevice, h->sc[h->cur].s);
         if (e != hipSuccess) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(H2D): %s", hipGetErrorString(e));
+        if (ntr < 38) tr[ntr++] = us();
         if (!rc) rc = forward_tiles_dev(h, d_t, n, (float*)h->ws_out.p + (size_t)lo * h->P);
+        if (ntr < 38) tr[ntr++] = us();
     }
     // downloads are enqueued after ALL launches: a pageable D2H blocks the host until its chunk is done
     for (int k = 0; k < nchunks && !rc; ++k) {
-        const int64_t lo = B * k / nchunks, n = B * (k + 1) / nchunks - lo;
+        const int64_t lo = bound(k), n = bound(k + 1) - lo;
         h->cur = nchunks > 1 ? (k & 1) : cur0;
         hipError_t e = hipMemcpyAsync(out_host + (size_t)lo * h->P, (float*)h->ws_out.p + (size_t)lo * h->P,
                                       (size_t)n * h->P * sizeof(float), hipMemcpyDeviceToHost, h->sc[h->cur].s);
         if (e != hipSuccess) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(D2H): %s", hipGetErrorString(e));
+        if (ntr < 38) tr[ntr++] = us();
     }
     h->overlap = false;
     h->cur = cur0;
     const int rs = sync_all(h);
+    if (h->trace_host) {
+        std::fprintf(stderr, "msiren_forward_tiles B=%lld chunks=%d (us since entry): ", (long long)B, nchunks);
+        for (int k = 0; k < nchunks; ++k) std::fprintf(stderr, "h2d%d %.0f launched%d %.0f  ", k, tr[2 * k], k, tr[2 * k + 1]);
+        for (int k = 0; k < nchunks; ++k) std::fprintf(stderr, "d2h%d %.0f  ", k, tr[2 * nchunks + k]);
+        std::fprintf(stderr, "synced %.0f\n", us());
+    }
     return rc ? rc : rs;
 }
 
@@ -1752,6 +1791,7 @@ int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int6
 static int msiren_reconstruct_slices_impl(msiren_handle h, const float* images_host, int64_t n, int32_t height, int32_t width, float* recon_host) {
     int rc = check(h);
     if (rc) return rc;
+    SoloCall solo(h);
     if (n < 0 || (n > 0 && (!images_host || !recon_host))) return fail(MSIREN_E_INVALID, "bad arguments");
     if (n == 0) return 0;
     int32_t nV, nH;

@@ -42,8 +42,7 @@ def chain_info(m):
 
 
 def tiles_dev(m, tiles):
-    """msiren_forward_tiles_dev on resident tiles: the single-stream device path (host-pointer calls of >= 256 tiles cut
-    themselves in two chunks on two streams, where the per-layer launches stay)."""
+    """msiren_forward_tiles_dev on resident tiles: the single-stream device path."""
     B = tiles.shape[0]
     d_t = m.device_array(tiles.shape).copy_from(tiles)
     d_o = m.device_array((B, 24, 24))
@@ -101,8 +100,8 @@ def test_chain_against_reference_fixture():
 
 
 def test_chain_many_launches_of_changing_shape(pair):
-    """The stage counters are never reset: hundreds of launches with different stage lists (tiles / latent entry), batch
-    sizes and the host call's own path in between must keep every hand-off target right."""
+    """Hundreds of launches with different stage lists (tiles / latent entry) and batch sizes, each with an epoch of its own
+    over the same exchange buffers: a granule of an earlier launch must never pass for a current one."""
     on, off = pair
     rng = np.random.default_rng(5)
     ref = {}
@@ -156,7 +155,7 @@ def test_chain_that_gives_up_is_loud_then_per_layer():
     assert active == 0 and events >= 1
     assert np.array_equal(tiles_dev(m, tiles), ref)
     m2 = make(sd, True, spin=0)
-    small = tiles[:100]   # below the host call's two-chunk threshold: single stream, chain first
+    small = tiles[:100]   # the host call runs on one stream: chain first, then its own re-run with a launch per layer
     for _ in range(20):
         assert np.array_equal(m2(small), ref[:100])
     assert chain_info(m2)[1] >= 1
