@@ -180,6 +180,16 @@ MSIREN_API int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev 
  * to get the images it scores against (error.py:250-255). */
 MSIREN_API int msiren_patches_to_image_dev(msiren_handle h, const float* tiles_dev /* (n*nV*nH, O, O) */, int64_t n_slices,
                                 int32_t n_vertical, int32_t n_horizontal, float* image_dev);
+/* The black-patch filter of the reference's callers as separate steps (src/util/tiling.py:184-198, 244-303; used one by one in
+ * src/train/training.py:438-445 -- msiren_reconstruct_tiles_dev does all of them in one call).  All on the handle's current
+ * stream; tiles / rows float32, flags / indices int32, everything device memory.
+ *   msiren_black_patch_flags_dev  flags[t] = 1 where mean(tile t) < 1e-10 (classify_patches; a tile of 1e-12 is black), else 0
+ *   msiren_gather_rows_dev        dst[j] = src[idx[j]], j < n_idx            (patches[non_black_indices])
+ *   msiren_scatter_rows_dev       dst = zeros(n_rows); dst[idx[j]] = src[j]  (reintegrate_black_patches: black rows stay zeros) */
+MSIREN_API int msiren_black_patch_flags_dev(msiren_handle h, const float* tiles_dev, int64_t n_tiles, int64_t tile_elems, int32_t* flags_dev);
+MSIREN_API int msiren_gather_rows_dev(msiren_handle h, const float* src_dev, const int32_t* idx_dev, int64_t n_idx, int64_t row_elems, float* dst_dev);
+MSIREN_API int msiren_scatter_rows_dev(msiren_handle h, const float* src_dev, const int32_t* idx_dev, int64_t n_idx, int64_t n_rows, int64_t row_elems,
+                                       float* dst_dev);
 
 /* Pipelining of asynchronous calls.  n = 1 (default): every *_dev call is enqueued on one stream and
  * executes in call order.  n = 2: consecutive *_dev FORWARD calls (forward_mods/latent/tiles_dev,

@@ -77,6 +77,9 @@ PROTOTYPES = {
     "msiren_image_to_patches_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "msiren_weighted_fold_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "msiren_patches_to_image_dev": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "msiren_black_patch_flags_dev": (C.c_int, [_vp, _vp, _i64, _i64, _vp]),
+    "msiren_gather_rows_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "msiren_scatter_rows_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "msiren_sync": (C.c_int, [_vp]),
     "msiren_set_streams": (C.c_int, [_vp, _i32]),
     "msiren_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),

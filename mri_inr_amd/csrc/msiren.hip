@@ -1710,6 +1710,42 @@ int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev, int64_t n,
     return 0;
 }
 
+int msiren_black_patch_flags_dev(msiren_handle h, const float* tiles_dev, int64_t n_tiles, int64_t tile_elems, int32_t* flags_dev) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (n_tiles < 0 || tile_elems < 1 || tile_elems > (1 << 24) || (n_tiles > 0 && (!tiles_dev || !flags_dev))) return fail(MSIREN_E_INVALID, "bad arguments");
+    if (n_tiles == 0) return 0;
+    if (n_tiles > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "too many tiles for one call: %lld", (long long)n_tiles);
+    hipLaunchKernelGGL(msiren::black_flags_kernel, dim3((unsigned)n_tiles), dim3(256), 0, h->sc[h->cur].s, tiles_dev, flags_dev, (int)tile_elems);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int copy_rows(msiren_handle h, const float* src, const int32_t* idx, int64_t n_idx, int64_t row_elems, float* dst, int scatter) {
+    if (n_idx == 0) return 0;
+    if (n_idx > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "too many rows for one call: %lld", (long long)n_idx);
+    hipLaunchKernelGGL(msiren::copy_rows_kernel, dim3((unsigned)n_idx), dim3(256), 0, h->sc[h->cur].s, src, dst, idx, (int)row_elems, scatter);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int msiren_gather_rows_dev(msiren_handle h, const float* src_dev, const int32_t* idx_dev, int64_t n_idx, int64_t row_elems, float* dst_dev) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (n_idx < 0 || row_elems < 1 || row_elems > (1 << 24) || (n_idx > 0 && (!src_dev || !idx_dev || !dst_dev))) return fail(MSIREN_E_INVALID, "bad arguments");
+    return copy_rows(h, src_dev, idx_dev, n_idx, row_elems, dst_dev, 0);
+}
+
+int msiren_scatter_rows_dev(msiren_handle h, const float* src_dev, const int32_t* idx_dev, int64_t n_idx, int64_t n_rows, int64_t row_elems, float* dst_dev) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (n_idx < 0 || n_rows < n_idx || row_elems < 1 || row_elems > (1 << 24) || (n_rows > 0 && !dst_dev) || (n_idx > 0 && (!src_dev || !idx_dev)))
+        return fail(MSIREN_E_INVALID, "bad arguments");
+    if (n_rows == 0) return 0;
+    HIPCHK(hipMemsetAsync(dst_dev, 0, (size_t)n_rows * row_elems * sizeof(float), h->sc[h->cur].s));  // rows no index names stay zeros
+    return copy_rows(h, src_dev, idx_dev, n_idx, row_elems, dst_dev, 1);
+}
+
 int msiren_patches_to_image_dev(msiren_handle h, const float* tiles_dev, int64_t n, int32_t nV, int32_t nH, float* image_dev) {
     int rc = check(h, false);
     if (rc) return rc;

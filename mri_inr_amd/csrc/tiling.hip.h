@@ -96,6 +96,17 @@ __global__ __launch_bounds__(256) void compact_flags_kernel(const int* __restric
     }
 }
 
+// filter_and_remember_black_patches' `patches[non_black_indices]` (tiling.py:268) and reintegrate_black_patches' copy-back
+// (tiling.py:294-301) as row copies through an index list: gather: dst[j] = src[idx[j]]; scatter: dst[idx[j]] = src[j]
+// (the caller zero-fills dst first: black rows stay zeros).  One workgroup per row.
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ idx,
+                                                        int elems, int scatter) {
+    const int j = blockIdx.x, r = idx[j];
+    const float* s = src + (size_t)(scatter ? j : r) * elems;
+    float* d = dst + (size_t)(scatter ? r : j) * elems;
+    for (int i = threadIdx.x; i < elems; i += 256) d[i] = s[i];
+}
+
 // patches_to_image_weighted_average (tiling.py:91-140): fold(tiles * w) / fold(w) with kernel S,
 // stride I, padding `pad`.  Black patches (flags[b] != 0) contribute zeros with their full weight,
 // as reintegrate_black_patches + fold do in the reference (tiling.py:287-301, :117-118).

@@ -19,6 +19,10 @@ reconstruction and the folded fully-sampled image come back once, for the host-s
 
 ``visual_error`` (src/util/error.py:104-183) is the same chain for ONE slice with images written instead of scores.
 
+The steps of that chain also exist one by one, as the reference's callers spell them (src/train/training.py:438-445,
+src/util/error.py:132-152): ``filter_and_remember_black_patches`` -> ``model(...)`` -> ``reintegrate_black_patches`` ->
+``patches_to_image_weighted_average`` (tiling.py:244-303, 91-140).  ``reconstruct_from_patches`` does the four in one device call.
+
 ``metrics_error`` does what the reference does, in its order: black-tile filter -> model on the kept tiles -> zeros
 re-inserted -> weighted overlap-add of the 24x24 outputs; the fully-sampled tiles folded with the plain overlap
 average give the image the reconstruction is scored against (error.py:251-254) -- not the raw slice: on sizes that
@@ -101,6 +105,70 @@ def patches_to_image(tiles, image_information, outer_patch_size, inner_patch_siz
         raise ValueError(f"tiles {d_t.shape} do not match image_information {image_information[0]}")
     d_o = model.device_array((n, nv * inner_patch_size, nh * inner_patch_size))
     _lib.check(model._lib.msiren_patches_to_image_dev(model._h, d_t.ptr, n, nv, nh, d_o.ptr))
+    model.sync()
+    return d_o.numpy() if host else d_o
+
+
+def _int_device(model, a):
+    """int32 numpy -> device (a DeviceArray holds 4-byte words: the bit patterns travel as they are)."""
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return model.device_array(a.shape).copy_from(a.view(np.float32))
+
+
+def filter_and_remember_black_patches(patches, *, model=None):
+    """(N, h, w) tiles -> (the non-black tiles in order, indices of the black ones, the original shape).  tiling.py:244-271;
+    black = mean < 1e-10 (classify_patches, :184-198), decided on the device; the index list is the only thing that
+    visits the host (the reference's is a Python list too)."""
+    model = _model(model)
+    model._ensure_committed()
+    d, host = _to_device(model, patches, 3)
+    n, hh, ww = d.shape
+    d_flags = model.device_array((max(n, 1),))
+    _lib.check(model._lib.msiren_black_patch_flags_dev(model._h, d.ptr, n, hh * ww, d_flags.ptr))
+    model.sync()
+    flags = d_flags.numpy().view(np.int32)[:n]
+    black_indices = [int(i) for i in np.nonzero(flags)[0]]
+    keep = np.nonzero(flags == 0)[0].astype(np.int32)
+    d_keep = model.device_array((len(keep), hh, ww))
+    if len(keep):
+        d_idx = _int_device(model, keep)
+        _lib.check(model._lib.msiren_gather_rows_dev(model._h, d.ptr, d_idx.ptr, len(keep), hh * ww, d_keep.ptr))
+        model.sync()
+    return (d_keep.numpy() if host else d_keep), black_indices, (n, hh, ww)
+
+
+def reintegrate_black_patches(processed_patches, black_indices, original_shape, *, model=None):
+    """Processed non-black tiles back at their positions, zeros where the black ones were.  tiling.py:274-303."""
+    model = _model(model)
+    model._ensure_committed()
+    d, host = _to_device(model, processed_patches, 3)
+    n_keep, hh, ww = d.shape
+    n = int(original_shape[0])
+    black = np.zeros(n, dtype=bool)
+    black[np.asarray(black_indices, dtype=np.int64)] = True
+    keep = np.nonzero(~black)[0].astype(np.int32)
+    if len(keep) != n_keep:
+        raise ValueError(f"{n_keep} processed tiles for {len(keep)} non-black positions of {n}")
+    d_full = model.device_array((n, hh, ww))
+    d_idx = _int_device(model, keep if len(keep) else np.zeros(1, np.int32))
+    _lib.check(model._lib.msiren_scatter_rows_dev(model._h, d.ptr, d_idx.ptr, n_keep, n, hh * ww, d_full.ptr))
+    model.sync()
+    return d_full.numpy() if host else d_full
+
+
+def patches_to_image_weighted_average(patches, image_information, patch_size, inner_patch_size, device=None, *, model=None):
+    """Weighted overlap-add of the (N, S, S) model outputs -> (n, nV*I, nH*I).  tiling.py:91-140 (weights :67-88)."""
+    model = _model(model)
+    if (patch_size, inner_patch_size) != (model.siren_patch_size, model.inner_patch_size):
+        raise ValueError(f"patch sizes ({patch_size}, {inner_patch_size}) differ from the model's ({model.siren_patch_size}, {model.inner_patch_size})")
+    model._ensure_committed()
+    d, host = _to_device(model, patches, 3)
+    nv, nh = image_information[0]
+    n = d.shape[0] // (nv * nh)
+    if d.shape != (n * nv * nh, patch_size, patch_size):
+        raise ValueError(f"tiles {d.shape} do not match image_information {image_information[0]}")
+    d_o = model.device_array((n, nv * inner_patch_size, nh * inner_patch_size))
+    _lib.check(model._lib.msiren_weighted_fold_dev(model._h, d.ptr, n, nv, nh, d_o.ptr))
     model.sync()
     return d_o.numpy() if host else d_o
 

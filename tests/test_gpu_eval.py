@@ -137,3 +137,51 @@ def test_harness_mirror_matches_oracle_tiling():
     assert np.array_equal(rec, m.reconstruct(imgs))              # same chain as the slice entry point, bit for bit
     with pytest.raises(ValueError):
         harness.image_to_patches(imgs, 32, 8)
+
+
+def test_harness_black_filter_steps_one_by_one():
+    """The reference's callers spell the chain step by step (training.py:438-445, error.py:132-152):
+    filter_and_remember_black_patches -> model -> reintegrate_black_patches -> patches_to_image_weighted_average.  Each step
+    against the oracle's restatement, the composition bit for bit against the one-call form; numpy in -> numpy out and
+    DeviceArray in -> DeviceArray out."""
+    from mri_inr_amd import ModulatedSiren, harness
+
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = ModulatedSiren(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda", activation="sine")
+    m.load_state_dict(sd)
+    m.to("cuda").eval()
+    harness.bind(m)
+    img = syn.make_slice(4, 200, 136, brain_mask=True)
+    img[:40] = 0.0
+    tiles, info = harness.image_to_patches(img[None], 32, 16)
+    tiles[5] = 1e-12                                              # mean < 1e-10 counts as black (tiling.py:184-198)
+    kept, black, shape = harness.filter_and_remember_black_patches(tiles)
+    o_kept, o_black, o_shape = orc.filter_and_remember_black_patches(tiles)
+    assert black == [int(i) for i in o_black] and 5 in black and 0 < len(black) < tiles.shape[0]
+    assert tuple(shape) == tuple(o_shape) == tiles.shape and np.array_equal(kept, o_kept)
+    out = m(kept)                                                 # (n_keep, 24, 24)
+    full = harness.reintegrate_black_patches(out, black, shape)
+    assert full.shape == (tiles.shape[0], 24, 24)
+    assert np.array_equal(full, orc.reintegrate_black_patches(out, o_black, (tiles.shape[0], 24, 24)))
+    rec = harness.patches_to_image_weighted_average(full, info, 24, 16, "cuda")
+    assert np.abs(rec[0] - orc.patches_to_image_weighted_average(full, info[0], 24, 16)).max() < 1e-6
+    assert np.array_equal(rec, harness.reconstruct_from_patches(m, tiles, info))   # the one-call form: same bits
+    # device-resident: nothing but the index list visits the host
+    d_tiles = m.device_array(tiles.shape).copy_from(tiles)
+    d_kept, black2, shape2 = harness.filter_and_remember_black_patches(d_tiles)
+    assert black2 == black and tuple(shape2) == tuple(shape) and np.array_equal(d_kept.numpy(), kept)
+    d_full = harness.reintegrate_black_patches(m.device_array(out.shape).copy_from(out), black2, shape2)
+    assert np.array_equal(d_full.numpy(), full)
+    assert np.array_equal(harness.patches_to_image_weighted_average(d_full, info, 24, 16, "cuda").numpy(), rec)
+    # all black / none black
+    z_kept, z_black, _ = harness.filter_and_remember_black_patches(np.zeros((3, 32, 32), np.float32))
+    assert z_kept.shape == (0, 32, 32) and z_black == [0, 1, 2]
+    back = harness.reintegrate_black_patches(np.zeros((0, 24, 24), np.float32), z_black, (3, 32, 32))
+    assert back.shape == (3, 24, 24) and not back.any()
+    ones = np.ones((2, 32, 32), np.float32)
+    n_kept, n_black, _ = harness.filter_and_remember_black_patches(ones)
+    assert n_black == [] and np.array_equal(n_kept, ones)
+    with pytest.raises(ValueError):
+        harness.reintegrate_black_patches(out[:-1], black, shape)
