@@ -148,6 +148,13 @@ MSIREN_API int msiren_forward_mods_dev(msiren_handle h, const float* mods_dev, i
 MSIREN_API int msiren_forward_latent(msiren_handle h, const float* z_host, int64_t B, float* out_host, float* mods_out_host);
 MSIREN_API int msiren_forward_latent_dev(msiren_handle h, const float* z_dev, int64_t B, float* out_dev, float* mods_out_dev);
 
+/* The two producers alone, as the reference exposes them as sub-modules: `model.encoder(tiles)` -> latent (B, Z)
+ * (modulated_siren.py:420, 282-301; siren_encoder.py:565-577) and `model.modulator(z)` -> the L modulation vectors, stacked
+ * (L, B, H) (modulated_siren.py:416, 325-343).  msiren_forward_tiles == trunk(modulate(encode(tiles))), bit for bit. */
+MSIREN_API int msiren_encode_tiles(msiren_handle h, const float* tiles_host, int64_t B, float* latent_host);
+MSIREN_API int msiren_encode_tiles_dev(msiren_handle h, const float* tiles_dev, int64_t B, float* latent_dev);
+MSIREN_API int msiren_modulate(msiren_handle h, const float* latent_host, int64_t B, float* mods_host);
+MSIREN_API int msiren_modulate_dev(msiren_handle h, const float* latent_dev, int64_t B, float* mods_dev);
 /* ModulatedSiren.forward (modulated_siren.py:435-457), custom-encoder branch
  * (siren_encoder.py:503-512,565-577): tiles (B,O,O) -> out (B,S,S). */
 MSIREN_API int msiren_forward_tiles(msiren_handle h, const float* tiles_host, int64_t B, float* out_host);

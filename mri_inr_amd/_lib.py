@@ -66,6 +66,10 @@ PROTOTYPES = {
     "msiren_weights_import": (C.c_int, [_vp, _vp, C.c_size_t]),
     "msiren_forward_mods": (C.c_int, [_vp, _vp, _i64, _vp]),
     "msiren_forward_mods_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "msiren_encode_tiles": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "msiren_encode_tiles_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "msiren_modulate": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "msiren_modulate_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
     "msiren_forward_latent": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "msiren_forward_latent_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "msiren_forward_tiles": (C.c_int, [_vp, _vp, _i64, _vp]),

@@ -1594,6 +1594,59 @@ int msiren_forward_latent(msiren_handle h, const float* z_host, int64_t B, float
     return with_range_fallback(h, [&] { return msiren_forward_latent_impl(h, z_host, B, out_host, mods_out_host); });
 }
 
+// ---- the two producers alone: model.encoder(tiles) and model.modulator(z) of the reference (modulated_siren.py:420, 416) ----
+int msiren_encode_tiles_dev(msiren_handle h, const float* tiles_dev, int64_t B, float* z_dev) {
+    int rc = check(h);
+    if (rc) return rc;
+    next_stream(h);
+    if (B < 0 || (B > 0 && (!tiles_dev || !z_dev))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
+    if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles (siren_encoder.py:499), outer_patch_size=%d", h->O);
+    return launch_encoder(h, tiles_dev, B, z_dev);
+}
+
+int msiren_modulate_dev(msiren_handle h, const float* z_dev, int64_t B, float* mods_dev) {
+    int rc = check(h);
+    if (rc) return rc;
+    next_stream(h);
+    if (B < 0 || (B > 0 && (!z_dev || !mods_dev))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
+    return launch_modulator(h, z_dev, B, mods_dev);
+}
+
+int msiren_encode_tiles(msiren_handle h, const float* tiles_host, int64_t B, float* z_host) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!tiles_host || !z_host))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
+    if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles (siren_encoder.py:499), outer_patch_size=%d", h->O);
+    if (B == 0) return 0;
+    const size_t nt = (size_t)B * h->O * h->O * sizeof(float), nz = (size_t)B * h->Z * sizeof(float);
+    auto& c = h->sc[h->cur];
+    if ((rc = ensure(h, h->ws_tiles, nt)) || (rc = ensure(h, c.latent, nz))) return rc;
+    HIPCHK(hipMemcpyAsync(h->ws_tiles.p, tiles_host, nt, hipMemcpyHostToDevice, c.s));
+    if ((rc = launch_encoder(h, (const float*)h->ws_tiles.p, B, (float*)c.latent.p))) return rc;
+    HIPCHK(hipMemcpyAsync(z_host, c.latent.p, nz, hipMemcpyDeviceToHost, c.s));
+    HIPCHK(hipStreamSynchronize(c.s));
+    return 0;
+}
+
+int msiren_modulate(msiren_handle h, const float* z_host, int64_t B, float* mods_host) {
+    int rc = check(h);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!z_host || !mods_host))) return fail(MSIREN_E_INVALID, "bad arguments (B=%lld)", (long long)B);
+    if (B == 0) return 0;
+    const size_t nz = (size_t)B * h->Z * sizeof(float), nm = (size_t)h->L * B * h->H * sizeof(float);
+    auto& c = h->sc[h->cur];
+    if ((rc = ensure(h, c.latent, nz)) || (rc = ensure(h, c.mods, nm))) return rc;
+    HIPCHK(hipMemcpyAsync(c.latent.p, z_host, nz, hipMemcpyHostToDevice, c.s));
+    if ((rc = launch_modulator(h, (const float*)c.latent.p, B, (float*)c.mods.p))) return rc;
+    HIPCHK(hipMemcpyAsync(mods_host, c.mods.p, nm, hipMemcpyDeviceToHost, c.s));
+    HIPCHK(hipStreamSynchronize(c.s));
+    if (take_chain_flag(h)) {  // (opt-in one-launch form gave up: run the layers as launches)
+        h->chain_rerun_pending = false;
+        return msiren_modulate(h, z_host, B, mods_host);
+    }
+    return 0;
+}
+
 int msiren_forward_tiles_dev(msiren_handle h, const float* tiles_dev, int64_t B, float* out_dev) {
     int rc = check(h);
     if (rc) return rc;

@@ -370,6 +370,50 @@ class ModulatedSiren:
         return self._run(self._lib.msiren_forward_mods, self._lib.msiren_forward_mods_dev, mods,
                          (self.num_layers, None, self.dim_hidden), lambda s: s[1])
 
+    # ---- the reference's sub-modules as callables: model.encoder(tiles), model.modulator(z), model.net(coords, mods) ----
+    def _host_call(self, fn, x, in_tail, out_shape):
+        self._ensure_committed()
+        torch_in = _is_torch(x)
+        a = x.detach().cpu().numpy() if torch_in else np.asarray(x)
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        self._check_tail(a.shape, in_tail)
+        out = np.empty(out_shape(a.shape), dtype=np.float32)
+        _lib.check(fn(self._h, a.ctypes.data if a.size else None, a.shape[0], out.ctypes.data if out.size else None))
+        if torch_in:
+            import torch
+
+            return torch.from_numpy(out)
+        return out
+
+    def encoder(self, tiles):
+        """tiles (B, O, O) -> latent (B, Z): the reference's ``model.encoder(tiles)`` (modulated_siren.py:420, 282-301)."""
+        if self.encoder_type != "custom":
+            raise AttributeError("'Encoder' object has no attribute 'encoder'")  # as the reference fails
+        self._ensure_handle()
+        O = self.outer_patch_size
+        return self._host_call(self._lib.msiren_encode_tiles, tiles, (None, O, O), lambda s: (s[0], self.latent_dim))
+
+    def modulator(self, z):
+        """latent (B, Z) -> tuple of num_layers arrays (B, H): the reference's ``model.modulator(z)`` (modulated_siren.py:416,
+        325-343; it returns a tuple, hidden layer by hidden layer)."""
+        self._ensure_handle()
+        stacked = self._host_call(lambda h, a, B, o: self._lib.msiren_modulate(h, a, B, o), z, (None, self.latent_dim),
+                                  lambda s: (self.num_layers, s[0], self.dim_hidden))
+        # msiren_modulate's batch argument is the latent's first dimension; the output is (L, B, H)
+        return tuple(stacked[l] for l in range(self.num_layers))
+
+    def net(self, coords, mods):
+        """``SirenNet.forward(coords, mods)`` (modulated_siren.py:215-233) -> (B, P, 1).  The trunk kernels evaluate the model's
+        own coordinate grid (the only coordinates the reference ever passes, :447-450): ``coords`` must be None or that grid
+        repeated over the batch."""
+        if coords is not None:
+            c = coords.detach().cpu().numpy() if _is_torch(coords) else np.asarray(coords)
+            g = np.asarray(self.grid, dtype=np.float32)
+            if c.shape[-2:] != g.shape or not np.array_equal(np.broadcast_to(g, c.shape), c.astype(np.float32)):
+                raise ValueError("net(coords, mods): the trunk evaluates the model's own grid only (pass coords=None or model.grid repeated over the batch)")
+        out = self.forward_mods(mods)
+        return out.reshape(out.shape[0], -1, 1)
+
     def reconstruct(self, images):
         """images (n, Hh, Ww) or (Hh, Ww) -> (n, nV*I, nH*I): the whole slice pipeline of
         metrics_error (src/util/error.py:231-249) on the device."""

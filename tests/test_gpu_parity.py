@@ -797,3 +797,33 @@ def test_tiling_roundtrip_property_on_device():
         m.sync()
         out = d_o.numpy()
         assert np.abs(out[:, :hh, :ww] - imgs).max() < 1e-6, (n, hh, ww)
+
+
+def test_submodules_encoder_modulator_net_like_the_reference():
+    """model.encoder(tiles), model.modulator(z), model.net(coords, mods): the reference's sub-modules (modulated_siren.py:404-425)
+    against the oracle, and forward == net(grid, modulator(encoder(tiles))) bit for bit."""
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = make_model(sd)
+    tiles = np.random.default_rng(12).random((70, 32, 32), dtype=np.float32)
+    z = m.encoder(tiles)
+    assert z.shape == (70, 256) and z.dtype == np.float32
+    assert nerr(z, orc.encoder_forward(sd, tiles, dtype=np.float64)) < 1e-5
+    mods = m.modulator(z)
+    assert isinstance(mods, tuple) and len(mods) == 5 and all(t.shape == (70, 256) for t in mods)
+    ref_mods = orc.modulator_forward(sd, z, num_layers=5, dtype=np.float64)
+    assert nerr(np.stack(mods), ref_mods) < 1e-5 and all((t >= 0).all() for t in mods)
+    coords = np.broadcast_to(np.asarray(m.grid, np.float32), (70,) + np.asarray(m.grid).shape)
+    out = m.net(coords, mods)
+    assert out.shape == (70, 576, 1)
+    assert np.array_equal(out.reshape(70, 24, 24), m(tiles))      # the same three steps inside forward
+    assert np.array_equal(m.net(None, mods), out)
+    with pytest.raises(ValueError):
+        m.net(coords * 0.5, mods)
+    # small batch (fused per-tile encoder) and the empty batch
+    z1 = m.encoder(tiles[:3])
+    assert nerr(z1, orc.encoder_forward(sd, tiles[:3], dtype=np.float64)) < 1e-5
+    assert m.encoder(tiles[:0]).shape == (0, 256)
+    assert all(t.shape == (0, 256) for t in m.modulator(np.zeros((0, 256), np.float32)))
+    torch = pytest.importorskip("torch")
+    zt = m.encoder(torch.from_numpy(tiles))
+    assert isinstance(zt, torch.Tensor) and np.array_equal(zt.numpy(), z)
