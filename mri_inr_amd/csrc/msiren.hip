@@ -322,9 +322,9 @@ int pack_trunk_f16x3(msiren_ctx* h) {
         int e = 0;
         if (mx > 0.0) e = (int)std::floor(std::log2(16384.0 / mx));
         e = std::max(-14, std::min(e, 30));
-        const double sc = std::ldexp(c, e);
         h->winv16[l - 1] = (float)std::ldexp(1.0, -e);
 #ifdef MSIREN_WITH_TILE32
+        const double sc = std::ldexp(c, e);
         for (int t = 0; t < 8; ++t)
             for (int s = 0; s < 16; ++s)
                 for (int lane = 0; lane < 64; ++lane)

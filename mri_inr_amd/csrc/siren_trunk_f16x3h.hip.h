@@ -28,7 +28,6 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
     const int L = p.L;
     const int nchunks = (L - 1) * 8;
 
-    const unsigned char* l0B = smem + LY::l0 + q * 64;
     const unsigned char* woutB = smem + LY::wout + q * 16;
     const unsigned char* zeroB = smem + LY::zero + q * 16;
     const unsigned char* biasB = smem + LY::bias + q * 16;

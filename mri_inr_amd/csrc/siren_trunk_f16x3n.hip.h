@@ -94,7 +94,6 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
     const int nchunks = (L - 1) * 8;
 
     // Per-lane byte bases of the LDS tables: every access below is `base + compile-time constant`.
-    const unsigned char* l0B = smem + LY::l0 + q * 64;      // float4 per feature, features 4q..
     const unsigned char* woutB = smem + LY::wout + q * 16;  // float per feature
     const unsigned char* zeroB = smem + LY::zero + q * 16;
     const unsigned char* biasB = smem + LY::bias + q * 16;

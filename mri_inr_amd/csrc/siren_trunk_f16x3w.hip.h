@@ -133,7 +133,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     // ---- per-lane bases (every LDS access below is base + compile-time constant, or + one per-slot scalar) -----------
     unsigned char* const actL = smem + LY::act + lane * 16;                       // + unit * 32768 + fragment offset
     const unsigned char* const biasL = smem + LY::bias + wave * 256 + q * 16;     // + (l-1) * 1024 + t * 64
-    const unsigned char* const woutL = smem + LY::wout(L) + wave * 256 + q * 16;  // + t * 64
     unsigned char* const modsW = smem + LY::mods(L) + wave * 256;                 // this wave's 64 features of a row
     const unsigned char* const modsL = modsW + q * 16;                            // + (unit * (L+1) + row) * 1024 + t * 64
     float* const redW = reinterpret_cast<float*>(smem + LY::red(L));              // [parity][coordinate 0..31][wave]
@@ -595,7 +594,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
 
 #define MSIREN_WS_REGION(PAR, VAR, FL, S)                                                                            \
     do {                                                                                                             \
-        constexpr int PP_ = (PAR) ^ 1;                                                                               \
+        [[maybe_unused]] constexpr int PP_ = (PAR) ^ 1; /* (the accumulator set the epilogue in the gaps reads) */     \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         MSIREN_WS_HOLD();                                                                                            \
         if ((FL) == 0) MSIREN_WS_WAITK(S);                                                                           \
