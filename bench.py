@@ -102,17 +102,19 @@ def effective_cores() -> int:
 
 
 def traffic_bytes(kernel):
-    """HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes (collected with
-    tools/profile.sh: separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction); None if no profile on
-    record is for this kernel."""
-    for rnd in ("r3", "r2", "r1"):
+    """HBM/fabric bytes per launch of a trunk instance from the committed PMC passes (collected with tools/profile.sh:
+    separate --pmc runs, FETCH_SIZE doubled per the gfx950 correction): the newest profile on record that names this
+    instance, as {"bytes_per_launch", "source"}; None if there is none."""
+    if not kernel:
+        return None
+    for rnd in ("r4", "r3", "r2", "r1"):
         try:
             d = json.load(open(os.path.join(REPO, "profiles", rnd, "traffic.json")))
         except Exception:
             continue
         for e in d.get("kernels", [d]):
             if e.get("kernel") == kernel:
-                return e["bytes_per_launch"]
+                return {"bytes_per_launch": e["bytes_per_launch"], "source": e.get("source", f"profiles/{rnd}/traffic.json")}
     return None
 
 
@@ -375,12 +377,11 @@ def main():
     _lib.check(lib.msiren_timer_stop(h, C.byref(dev_ms)))
     launches, trunk_ms = C.c_int64(), C.c_double()
     _lib.check(lib.msiren_profile_read(h, C.byref(launches), C.byref(trunk_ms)))
+    timed_kernels = model.profile_kernels()   # what the timed region launched, as the library names it
     _lib.check(lib.msiren_profile_enable(h, 0))
     elapsed_local = t1 - t0
     group.barrier()
     elapsed = group.max(elapsed_local)
-    overlapped_trunk_ms = trunk_ms.value / max(launches.value, 1)
-    n_over = int(launches.value)
 
     if args.streams > 1 and B > 0:
         # With two streams the launches of consecutive steps overlap, so a launch's own duration says
@@ -394,8 +395,11 @@ def main():
         for _ in range(max(MIN_ROOFLINE_LAUNCHES, args.steps // 4) if n_sl <= 8 else max(20, args.steps // 4)):
             step()
         _lib.check(lib.msiren_profile_read(h, C.byref(launches), C.byref(trunk_ms)))
+        alone_kernels = model.profile_kernels()
         _lib.check(lib.msiren_profile_enable(h, 0))
         _lib.check(lib.msiren_set_streams(h, args.streams))
+    else:
+        alone_kernels = timed_kernels
 
     # behind the timed region and the roofline phase (the card is warm): the power-limited MFMA ceiling of this card
     sustained_tflops = sustained_mhz = None
@@ -410,38 +414,86 @@ def main():
     evaluated = B
     if args.pipeline == "reconstruct" and B:
         evaluated = int((d_tiles.numpy()[:B].reshape(B, -1).mean(axis=1, dtype=np.float32) >= np.float32(1e-10)).sum())
-    flops_launch = model.flops_per_coord() * evaluated * 576
-    trunk_avg_s = trunk_ms.value / max(launches.value, 1) / 1e3
-    achieved = flops_launch / trunk_avg_s / 1e12 if trunk_avg_s > 0 else 0.0
+    fpc = model.flops_per_coord()
+    flops_step = fpc * evaluated * 576          # algorithmic trunk FLOPs of one step on this rank
 
     if args.precision == "f16x3":
         # 3 fp16 MFMAs per algorithmic multiply-add: the bound for ALGORITHMIC FLOPs is the dense fp16
         # MFMA peak / 3.  The fp32-MFMA peak the north star names is reported next to it.
         dtype, peak = "f16x3", F16_MFMA_PEAK_TFLOPS / 3.0
         dtype_note = "split-fp16: hi/lo fp16 operands, three fp16 MFMAs per product, fp32 accumulate; fp32-equivalent accuracy (1e-4 gate)"
-        act_i = 1 if args.activation == "morlet" else 0
-        if os.environ.get("MSIREN_F16_TILE") == "32":   # A/B build (make AB32=1) with the 32x32x16 kernel selected
-            kernel = "siren_trunk_f16x3_kernel<%d,4>" % act_i
-        elif 3 <= L <= 5 and os.environ.get("MSIREN_F16_WS", "1") != "0":
-            # single-stream launches (the roofline phase) run the weight-stationary trunk; with two streams the timed region
-            # runs the register-resident one beside the next call's encoder / modulator (roofline_timed_mode.kernel)
-            kernel = "siren_trunk_f16x3w_kernel<%d,4>" % act_i
-        else:                                            # 16x16x32 tiles; the num_layers = 5 straight-line instance
-            kernel = "siren_trunk_f16x3n_kernel<%d,4,%d>" % (act_i, 5 if L == 5 else 0)
-        kernel_two_streams = "siren_trunk_f16x3n_kernel<%d,3,%d>" % (act_i, 5 if L == 5 else 0)
     elif args.precision in ("bf16", "f16"):
         dtype, peak = args.precision, F16_MFMA_PEAK_TFLOPS
         dtype_note = f"{args.precision} MFMA operands, fp32 accumulate"
-        kernel = "siren_trunk_x1_kernel<%d,%d,%d,3>" % (args.precision == "bf16", args.activation == "morlet", deep)
     else:
         dtype, peak = "f32", FP32_MFMA_PEAK_TFLOPS
         dtype_note = "fp32 MFMA (exact fp32 products and accumulation)"
-        kernel = "siren_trunk_f32_kernel<%d,%d,%d,0>" % (H, args.activation == "morlet", deep)
-    if dtype != "f16x3":
-        kernel_two_streams = kernel
+
+    def per_kernel(recs, masked_scale=1.0):
+        """[{kernel, launches, ms_total, coords}] (msiren_profile_read_kernel) -> the same with rates.  `coords` counts the
+        coordinates the launches were handed; in the masked slice pipeline only `evaluated / B` of them are evaluated."""
+        out = []
+        for r in recs:
+            fl = fpc * r["coords"] * masked_scale
+            tf = fl / (r["ms_total"] * 1e-3) / 1e12 if r["ms_total"] > 0 else 0.0
+            out.append({"kernel": r["kernel"], "launches": r["launches"], "avg_launch_ms": r["ms_total"] / max(r["launches"], 1),
+                        "flops_per_launch": fl / max(r["launches"], 1), "achieved": tf, "frac": tf / peak})
+        return out
+
+    mscale = (evaluated / B) if B else 1.0
+    timed_k, alone_k = per_kernel(timed_kernels, mscale), per_kernel(alone_kernels, mscale)
+    dom_timed = max(timed_k, key=lambda r: r["flops_per_launch"] * r["launches"]) if timed_k else None
+    dom_alone = max(alone_k, key=lambda r: r["flops_per_launch"] * r["launches"]) if alone_k else None
+    pipelined = flops_step * args.steps / elapsed_local / 1e12 if elapsed_local > 0 else 0.0   # this rank's trunk FLOPs / its timed wall
+
     stage = ("slice -> tiles -> black filter -> encoder+modulator+fused trunk -> weighted fold -> slice, device-resident"
              if args.pipeline == "reconstruct" else
              f"ModulatedSiren.forward (encoder+modulator+fused trunk, {args.activation}) on resident tiles -> (B,24,24) in HBM")
+    # The roofline block describes the kernel that RAN IN THE TIMED REGION (named by the library, msiren_profile_read_kernel).
+    #   one stream : the launches do not overlap -> algorithmic FLOPs of that instance's launches / their summed HIP-event time;
+    #   two streams: the launches of consecutive steps overlap (each event pair spans ~2 steps), so a launch's own duration
+    #                stops describing the kernel: achieved = the trunk FLOPs of the timed region / its wall time (encoder +
+    #                modulator of the other stream run beside the trunk and are inside that time; only trunk FLOPs counted),
+    #                avg_launch_ms = wall / launches; the event mean is kept beside it (it is what rocprofv3 --kernel-trace
+    #                shows for the overlapped launches).  roofline_kernel_alone: the single-stream phase behind the region.
+    if dom_timed is None:
+        roof = {"bound": "mfma", "achieved": 0.0, "peak": peak, "unit": "TFLOP/s", "frac": 0.0, "traffic": None, "kernel": None}
+    elif args.streams == 1:
+        roof = {"bound": "mfma", "achieved": dom_timed["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom_timed["frac"],
+                "kernel": dom_timed["kernel"], "flops_per_launch": dom_timed["flops_per_launch"],
+                "avg_launch_ms": dom_timed["avg_launch_ms"], "launches": dom_timed["launches"],
+                "measured": "HIP event pairs on the kernel's stream around every launch of this instance inside the timed region "
+                            "(one stream: launches do not overlap), rank 0"}
+    else:
+        n_l = sum(r["launches"] for r in timed_k)
+        roof = {"bound": "mfma", "achieved": pipelined, "peak": peak, "unit": "TFLOP/s", "frac": pipelined / peak,
+                "kernel": dom_timed["kernel"], "flops_per_launch": flops_step * args.steps / max(n_l, 1),
+                "avg_launch_ms": elapsed_local * 1e3 / max(n_l, 1), "launches": n_l,
+                "event_avg_launch_ms": dom_timed["avg_launch_ms"],
+                "measured": "two streams: consecutive steps' launches overlap, so achieved = trunk FLOPs of the timed region / its "
+                            "wall time and avg_launch_ms = wall / trunk launches (the figure consistent with `value`); "
+                            "event_avg_launch_ms = mean HIP-event span of one (overlapped) launch of this instance"}
+    tb = traffic_bytes(roof.get("kernel"))
+    roof.update({
+        "traffic": tb["bytes_per_launch"] if tb else None,
+        "traffic_source": (tb["source"] + " (rocprofv3 --pmc passes of this command in separate runs, FETCH_SIZE x2 per the gfx950 "
+                           "correction; one 320x320 slice per launch -- not measured in this run)") if tb else None,
+        # achieved fabric / HBM rate, to show how far from the 8 TB/s roof the kernel is (SURVEY.md §8d); only where the committed
+        # PMC profile applies: a 400-tile single-slice launch of the forward pipeline
+        "hbm_gb_s": (tb["bytes_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9)
+                    if (tb and roof.get("avg_launch_ms") and n_sl == 1 and evaluated == 400 and args.pipeline == "forward") else None,
+        "hbm_peak_gb_s": 8000.0,
+        "frac_of_fp32_mfma_peak": roof["achieved"] / FP32_MFMA_PEAK_TFLOPS,
+        "timed_region_kernels": timed_k,
+        # what this card sustains on nothing but the f16x3 trunk's MFMA stream with operands of the trunk's magnitudes, measured
+        # in this run behind the timed region (msiren_mfma_sustained_probe): the power-limited ceiling -- context for `frac`,
+        # which is against the NOMINAL peak
+        "sustained_fp16_mfma_tflops_measured": sustained_tflops,
+        "sustained_mfma_clock_mhz_equivalent": sustained_mhz,
+        "frac_of_sustained_mfma_rate": (roof["achieved"] / (sustained_tflops / 3.0)) if (sustained_tflops and dtype == "f16x3") else None,
+        "note": f"achieved = algorithmic FLOPs ({fpc:.0f} per coordinate at {H}x{L}) / time; for f16x3 the kernel issues 3x that "
+                "many fp16 MFMA FLOPs, hence peak = 2500/3",
+    })
     result = {
         "metric": f"Mpixels/sec reconstructed (320x320 slice, hidden={H}, {L} layers)",
         "value": value, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -469,42 +521,19 @@ def main():
             "ranks_hold_identical_weights": bool(sum_max == sum_min), "probe_checksum": probe_sum,
             "warmup_steps_run": warm_steps,
         },
-        "roofline": {
-            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": traffic_bytes(kernel), "kernel": kernel,
-            # achieved HBM/fabric rate of the kernel, to show how far from the 8 TB/s roof it is
-            # (only where the committed PMC profile applies: a full 400-tile single-slice launch of the forward pipeline)
-            "hbm_gb_s": (traffic_bytes(kernel) / trunk_avg_s / 1e9)
-                        if (traffic_bytes(kernel) and trunk_avg_s > 0 and n_sl == 1 and evaluated == 400 and args.pipeline == "forward") else None,
-            "hbm_peak_gb_s": 8000.0,
-            "flops_per_launch": flops_launch, "avg_launch_ms": trunk_avg_s * 1e3, "launches": int(launches.value),
-            "frac_of_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-            # what this card sustains on nothing but the f16x3 trunk's MFMA stream with operands of the trunk's magnitudes,
-            # measured in this run behind the timed region (msiren_mfma_sustained_probe; round 1's standalone probe gave
-            # 1476 TFLOP/s): the power-limited ceiling -- context for `frac`, which is against the NOMINAL peak
-            "sustained_fp16_mfma_tflops_measured": sustained_tflops,
-            "sustained_mfma_clock_mhz_equivalent": sustained_mhz,
-            "frac_of_sustained_mfma_rate": (achieved / (sustained_tflops / 3.0)) if (sustained_tflops and dtype == "f16x3") else None,
-            "measured": ("HIP event pairs on the kernel's stream; single-stream phase of this run (kernel alone: what a handle with "
-                         "one stream launches), rank 0; the two-stream timed region launches " + kernel_two_streams +
-                         " (roofline_timed_mode)") if args.streams > 1 else
-                        "HIP event pairs on the kernel's stream inside the timed region, rank 0",
-            "timed_region_avg_launch_ms": overlapped_trunk_ms, "timed_region_launches": n_over,
-            "pipelined_tflops_per_gpu": model.flops_per_coord() * 576 * 400 * n_total * args.steps / elapsed / 1e12 / world,
-            "note": "achieved = algorithmic FLOPs (525824 per coordinate at 256x5) / mean kernel time; for f16x3 the "
-                    "kernel issues 3x that many fp16 MFMA FLOPs, hence peak = 2500/3",
-        },
+        "roofline": roof,
         "device_ms_per_step": dev_ms.value / args.steps,
     }
-    # The same figure for the mode `value` is measured in: with two streams the trunk launches of consecutive steps
-    # overlap, so what describes the timed region is the rate at which whole slices leave the pipeline (encoder and
-    # modulator included in the time, only the trunk's algorithmic FLOPs counted), not one launch's duration.
-    tm_achieved = result["roofline"]["pipelined_tflops_per_gpu"]
-    result["roofline_timed_mode"] = {
-        "bound": "mfma", "achieved": tm_achieved, "peak": peak, "unit": "TFLOP/s", "frac": tm_achieved / peak,
-        "streams": args.streams, "kernel": kernel_two_streams if args.streams > 1 and dtype == "f16x3" else kernel,
-        "measured": "trunk FLOPs of the timed region / its wall time (MAX over ranks), per GPU: the figure consistent with `value`",
-    }
+    if args.streams > 1 and dom_alone is not None:
+        # the dominant trunk instance of a ONE-stream handle on the same batch, alone on the device (single-stream phase of this
+        # process, behind the timed region): kernel quality without the pipelining
+        result["roofline_kernel_alone"] = {
+            "bound": "mfma", "achieved": dom_alone["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom_alone["frac"],
+            "kernel": dom_alone["kernel"], "flops_per_launch": dom_alone["flops_per_launch"],
+            "avg_launch_ms": dom_alone["avg_launch_ms"], "launches": dom_alone["launches"], "kernels": alone_k,
+            "frac_of_sustained_mfma_rate": (dom_alone["achieved"] / (sustained_tflops / 3.0)) if (sustained_tflops and dtype == "f16x3") else None,
+            "measured": "HIP event pairs on the kernel's stream, msiren_set_streams(h, 1) phase behind the timed region, rank 0",
+        }
 
     if rank == 0:
         if args.check and args.pipeline == "reconstruct":
@@ -523,10 +552,18 @@ def main():
             ref = orc.siren_forward(sd, mods, num_layers=L, activation=args.activation, residual=deep,
                                     dtype=np.float64).reshape(-1, 24, 24)
             result["check_nerr_vs_fp64_oracle"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+        tiles400 = d_tiles.numpy()[:400] if (world == 1 and not args.no_cpu_baseline and not deep) else None
         if world == 1 and not args.no_extras and not deep and n_sl >= 1:
             result["extra"] = extras(model, lib, h, _lib, d_img, d_tiles, d_recons, args.streams)
+            if args.pipeline == "forward" and not args.brain_mask and not args.total_slices and args.slices == 1 \
+                    and args.activation == "sine" and args.precision == "f16x3":
+                # the default (driver-run) line also carries every other BASELINE configuration, measured in this process
+                # behind the timed region: never `value`
+                for d in (d_img, d_tiles, *d_outs, *d_recons):
+                    d.free()
+                result["extra"]["configs"] = other_configs(sd, model, sustained_tflops)
         if world == 1 and not args.no_cpu_baseline and not deep:
-            result["cpu_baseline"] = cpu_baseline(sd, d_tiles.numpy()[:400], args.activation, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(sd, tiles400, args.activation, args.cpu_seconds)
         else:
             result["cpu_baseline"] = None
         info = model.device_info()
@@ -570,6 +607,112 @@ def extras(model, lib, h, _lib, d_img, d_tiles, d_recons, streams, budget_s=0.5)
     return {"host_to_host_mpixel_s": h2h, "reconstruct_mpixel_s": rec,
             "note": "one 320x320 slice per call, after the timed region: host numpy -> host numpy through "
                     "msiren_forward_tiles (PCIe-inclusive), and the device-resident slice -> slice pipeline"}
+
+
+def side_measure(model, n_slices, streams, steps, warmup, peak, seconds=0.25):
+    """One configuration beside the headline: `steps` timed msiren_forward_tiles_dev calls of n_slices x 400 resident tiles
+    (after `warmup` calls and until the card has been busy for `seconds`), then -- if streams == 2 -- a one-stream phase
+    for the kernel alone.  Returns value / ms per step / the trunk instances the library launched with their rates."""
+    from mri_inr_amd import _lib, synthetic as syn
+
+    lib, h = model._lib, model._h
+    B = n_slices * 400
+    imgs = np.stack([syn.make_slice(k) for k in range(n_slices)])
+    d_img, d_tiles = model.device_array(imgs.shape), model.device_array((B, 32, 32))
+    d_outs = [model.device_array((B, 24, 24)) for _ in range(2)]
+    d_img.copy_from(imgs)
+    _lib.check(lib.msiren_image_to_patches_dev(h, d_img.ptr, n_slices, 320, 320, d_tiles.ptr))
+    fpc = model.flops_per_coord()
+    k = [0]
+
+    def step():
+        _lib.check(lib.msiren_forward_tiles_dev(h, d_tiles.ptr, B, d_outs[k[0] & 1].ptr))
+        k[0] += 1
+
+    def phase(nstreams, n):
+        _lib.check(lib.msiren_set_streams(h, nstreams))
+        t_w = time.perf_counter()
+        for _ in range(warmup):
+            step()
+        model.sync()
+        while time.perf_counter() - t_w < seconds:
+            for _ in range(4):
+                step()
+            model.sync()
+        _lib.check(lib.msiren_profile_enable(h, 1))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        model.sync()
+        dt = time.perf_counter() - t0
+        recs = model.profile_kernels()
+        _lib.check(lib.msiren_profile_enable(h, 0))
+        ks = []
+        for r in recs:
+            tf = fpc * r["coords"] / (r["ms_total"] * 1e-3) / 1e12 if r["ms_total"] > 0 else 0.0
+            ks.append({"kernel": r["kernel"], "launches": r["launches"], "avg_launch_ms": r["ms_total"] / max(r["launches"], 1),
+                       "achieved_tflops": tf, "frac": tf / peak})
+        return dt, ks
+
+    dt, ks = phase(streams, steps)
+    timed_tf = fpc * B * 576 * steps / dt / 1e12
+    out = {"value": n_slices * 320 * 320 * steps / dt / 1e6, "unit": "Mpixel/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "slices_per_step": n_slices, "streams": streams, "timed_frac": timed_tf / peak, "timed_region_kernels": ks}
+    if streams == 2:
+        n1 = max(8, steps // 2)
+        dt1, ka = phase(1, n1)
+        out["kernel_alone"] = ka
+        out["one_stream"] = {"value": n_slices * 320 * 320 * n1 / dt1 / 1e6, "ms_per_step": dt1 / n1 * 1e3, "steps": n1,
+                             "timed_frac": fpc * B * 576 * n1 / dt1 / 1e12 / peak}
+    else:
+        out["kernel_alone"] = ks
+    dom = max(out["kernel_alone"], key=lambda r: r["achieved_tflops"] * r["avg_launch_ms"] * r["launches"])
+    out["kernel"], out["kernel_alone_frac"] = dom["kernel"], dom["frac"]
+    for d in (d_img, d_tiles, *d_outs):
+        d.free()
+    return out
+
+
+def other_configs(sd, model, sustained_tflops):
+    """BASELINE.json configs 3, 4, 5 and the exact-fp32 trunk at N = 1, measured in this process behind the headline's timed
+    region (device-resident tiles, as the headline; random-init weights of the named architecture)."""
+    from mri_inr_amd import ModulatedSiren, synthetic as syn
+
+    f16x3_peak = F16_MFMA_PEAK_TFLOPS / 3.0
+
+    def build(H, L, Z, act, prec, res, state):
+        m = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=1.0, w0_initial=30.0, use_bias=True,
+                           dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None, outer_patch_size=32,
+                           inner_patch_size=16, siren_patch_size=24, device=model.device_string(), activation=act,
+                           precision=prec, residual=res)
+        m.load_state_dict(state)
+        m.to(model.device_string()).eval()
+        return m
+
+    out = {}
+    # config 3 (the scaling configuration) on ONE GPU: 64 slices per call; and 8 slices per call (one rank's share of it on 8 GPUs)
+    out["config3_64_slices_n1"] = dict(side_measure(model, 64, 2, 12, 2, f16x3_peak), dtype="f16x3", peak_tflops=f16x3_peak,
+                                       workload="BASELINE configs[2]: 64 slices = 25600 tiles per call, one GPU")
+    out["config3_8_slices_per_rank"] = dict(side_measure(model, 8, 2, 60, 5, f16x3_peak), dtype="f16x3", peak_tflops=f16x3_peak,
+                                            workload="8 slices = 3200 tiles per call: one rank's share of configs[2] on 8 GPUs")
+    m4 = build(256, 5, 256, "morlet", "f16x3", False, sd)
+    out["config4_morlet"] = dict(side_measure(m4, 1, 2, 300, 20, f16x3_peak), dtype="f16x3", peak_tflops=f16x3_peak,
+                                 workload="BASELINE configs[3]: Morlet activation, one slice per call")
+    del m4
+    m32 = build(256, 5, 256, "sine", "fp32", False, sd)
+    out["fp32_trunk"] = dict(side_measure(m32, 1, 2, 150, 10, FP32_MFMA_PEAK_TFLOPS), dtype="f32", peak_tflops=FP32_MFMA_PEAK_TFLOPS,
+                             workload="configs[1] on the exact-fp32 trunk (v_mfma_f32_32x32x2_f32), one slice per call")
+    del m32
+    sd5 = syn.make_state_dict(seed=7, dim_hidden=512, num_layers=10, latent_dim=128, modulator_bias_center=0.25, encoder_gain=10.0)
+    m5 = build(512, 10, 128, "sine", "bf16", True, sd5)
+    out["config5_deep_residual_bf16"] = dict(side_measure(m5, 1, 2, 150, 10, F16_MFMA_PEAK_TFLOPS), dtype="bf16", peak_tflops=F16_MFMA_PEAK_TFLOPS,
+                                             workload="BASELINE configs[4]: deep residual 10x512, latent 128, bf16 MFMA (own semantics, "
+                                                      "parity unpinned), one slice per call")
+    del m5
+    out["note"] = ("each entry: `value` = its own timed region (two streams, tiles resident), never the headline's; `kernel` / "
+                   "`kernel_alone_frac` = dominant trunk instance of a one-stream phase as the library names it; "
+                   "`timed_frac` = trunk FLOPs of the entry's timed region / its wall time / peak_tflops")
+    return out
 
 
 if __name__ == "__main__":

@@ -203,7 +203,13 @@ MSIREN_API int msiren_scatter_rows_dev(msiren_handle h, const float* src_dev, co
  * reconstruct_slices_dev) alternate between two streams with private scratch, so independent calls
  * overlap on the device (the under-occupied tail of one call's trunk kernel is filled by the next
  * call's kernels).  The caller then must not hand the same output buffer to two consecutive calls,
- * nor feed one call's output to the next, without an msiren_sync() in between. */
+ * nor feed one call's output to the next, without an msiren_sync() in between.
+ *
+ * With n = 1, ONE large msiren_forward_tiles_dev call (>= 3200 tiles of a depth-5 split-fp16 model; environment
+ * MSIREN_SPLIT_MIN at msiren_create, 0 = never) overlaps with itself: the encoder + Modulator of most of its batch
+ * (`self.modulator(self.encoder(tiles))`, modulated_siren.py:446) run on the handle's other stream beside the trunk of
+ * the first 12 % of the batch, and the trunk of the rest follows on the call's stream.  Results are bit-identical to the
+ * uncut call (patches are independent); the call is complete when its stream is. */
 MSIREN_API int msiren_set_streams(msiren_handle h, int32_t n);
 
 /* Blocks until everything enqueued on the handle's streams has finished (the reference's implicit
@@ -254,6 +260,14 @@ MSIREN_API int msiren_timer_stop(msiren_handle h, float* elapsed_ms);
  * own event pair; msiren_profile_read returns launch count and summed milliseconds since enable. */
 MSIREN_API int msiren_profile_enable(msiren_handle h, int32_t on);
 MSIREN_API int msiren_profile_read(msiren_handle h, int64_t* launches, double* trunk_ms_total);
+/* The same, per trunk instance: entry `index` (0-based, in order of first launch since msiren_profile_enable(h, 1)) ->
+ * its name as launched (e.g. "siren_trunk_f16x3w_kernel<0,4>"), launch count, summed milliseconds and the coordinates
+ * (patches x siren_patch_size^2) its launches evaluated -- a large call is cut in two trunk launches of different kernels
+ * (below), so a roofline figure is per instance: msiren_flops_per_coord x coords_total / ms_total.  MSIREN_E_INVALID past
+ * the last entry.  msiren_last_trunk_kernel: the instance the most recent trunk launch of the handle used. */
+MSIREN_API int msiren_profile_read_kernel(msiren_handle h, int32_t index, char* name128, int64_t* launches, double* ms_total,
+                                          int64_t* coords_total);
+MSIREN_API int msiren_last_trunk_kernel(msiren_handle h, char* name128);
 
 /* name (<=255 chars + NUL), compute units, clock in MHz, total HBM bytes of the handle's device. */
 MSIREN_API int msiren_device_info(msiren_handle h, char* name256, int32_t* compute_units, int32_t* clock_mhz,
@@ -270,25 +284,12 @@ MSIREN_API int msiren_device_count(int32_t* count);
  * The reference's fp32 arithmetic (modulated_siren.py:215-233) has no such bound; this is what keeps "auto" precision from
  * returning inf / NaN where it would not.  msiren_range_events: launches that raised the flag since msiren_create. */
 MSIREN_API int msiren_range_events(msiren_handle h, int64_t* count);
-/* Opt-in (environment MSIREN_CHAIN=1 when the handle is created; single-stream handles, batches up to 512 tiles): the
- * Linear layers between the encoder's convolutions and the trunk -- conv3 == Linear(2048, 64), Linear(64, Z) and the L
- * Modulator layers, `self.modulator(self.encoder(tiles))` of modulated_siren.py:446 -- run as ONE launch (3 launches per
- * forward instead of 9).  Workgroups hand a layer's output to the next layer's workgroups inside the launch; results are
- * bit-identical to one launch per layer.  Measured no faster than the launches it replaces, hence
- * not the default.  A launch that had to give up a hand-off wait (its grid was not resident as a whole) raises a flag: a
- * host-pointer call then runs itself again with one launch per layer; after *_dev calls the next msiren_sync returns
- * MSIREN_E_HIP (outputs since the previous sync are not valid).  Either way the handle uses one launch per layer from
- * then on.  *active: 1 while the handle would use the single launch; *events: launches that gave up, since msiren_create. */
-MSIREN_API int msiren_chain_info(msiren_handle h, int32_t* active, int64_t* events);
 /* Diagnostic: the rate the device sustains on nothing but the split-fp16 trunk's MFMA stream (v_mfma_f32_16x16x32_f16, one wave
  * per SIMD on every CU, the trunk's three products per k-step on operands of the trunk's magnitudes), ~10 ms.  *tflops: fp16
  * MFMA TFLOP/s issued chip-wide (divide by 3 for the algorithmic figure of the f16x3 roofline); *mhz_equivalent (optional):
  * the clock at which one MFMA per 16 cycles and SIMD gives that rate.  What the nominal peak becomes under the power limit
  * on real data; bench.py reports it beside the roofline, never as `peak`. */
 MSIREN_API int msiren_mfma_sustained_probe(msiren_handle h, double* tflops, double* mhz_equivalent);
-/* Diagnostic: one msiren_forward_tiles_dev whose chain launch is stamped.  stamps_host: (clusters x 16 workgroups) x 17 uint64,
- * clusters = min(16, CUs / 16): [0] s_memrealtime (100 MHz) at the workgroup's start, [1 + s] after its stage s (0 = not run). */
-MSIREN_API int msiren_chain_timeline(msiren_handle h, const float* tiles_dev, int64_t B, float* out_dev, uint64_t* stamps_host);
 /* Algorithmic FLOPs per coordinate for the handle's configuration: 2*2*H + (L-1)*2*H*H + 2*H. */
 MSIREN_API int msiren_flops_per_coord(msiren_handle h, double* flops);
 MSIREN_API int msiren_abi_version(void);

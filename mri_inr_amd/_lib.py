@@ -94,11 +94,11 @@ PROTOTYPES = {
     "msiren_timer_stop": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "msiren_profile_enable": (C.c_int, [_vp, _i32]),
     "msiren_profile_read": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "msiren_profile_read_kernel": (C.c_int, [_vp, _i32, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "msiren_last_trunk_kernel": (C.c_int, [_vp, C.c_char_p]),
     "msiren_device_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_uint64)]),
     "msiren_flops_per_coord": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "msiren_range_events": (C.c_int, [_vp, C.POINTER(_i64)]),
-    "msiren_chain_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(_i64)]),
-    "msiren_chain_timeline": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "msiren_mfma_sustained_probe": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "msiren_comm_unique_id": (C.c_int, [_vp, C.c_size_t]),
     "msiren_comm_init_rank": (C.c_int, [_vp, _vp, C.c_size_t, _i32, _i32]),

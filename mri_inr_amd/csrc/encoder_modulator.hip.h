@@ -303,4 +303,91 @@ __global__ __launch_bounds__(256) void modulator_layer_mfma_kernel(ModulatorMfma
     }
 }
 
+// ---- the same Linear layer on (16 RT) x (16 FT) output tiles: throughput sizes ---------------------------------------
+// At a few thousand rows the 16 x 16 kernel above is bound by what it fetches, not by its MFMAs: every tile reads its own
+// 16 rows of the input and 16 rows of W in full (32 KB + 32 KB at K = 512 -- 1.6 GB per Modulator layer at 25 600 rows,
+// i.e. the L2s' whole bandwidth for 190 us; rocprofv3, profiles/r4/).  Here a workgroup owns RT x FT sub-tiles and every
+// fragment it loads feeds RT (weights) or FT (inputs) MFMAs: half the bytes per FLOP at 2 x 2.
+//
+// ARITHMETIC IS THAT OF THE 16 x 16 KERNEL, element for element: the same v_mfma_f32_16x16x4_f32 on the same k groups,
+// the same two accumulation chains per sub-tile (columns 0, 2 / 1, 3 of each 16-k block), K split over the four waves at
+// the same block boundaries, partial sums added in the same order ((r0 + r1) + r2) + r3 + bias -- so an output does not
+// depend on which of the two kernels (i.e. on how large a batch) produced it: bit-identical, tests/test_gpu_split.py.
+// Registers: 32 accumulators + two stages of 4 fragments at 2 x 2 -- under the 96 a kernel may use to run BESIDE the
+// register-resident trunk (tests/test_register_budget.py); LDS 16.5 KB.
+template <int RT, int FT>
+__global__ __launch_bounds__(256, 5) void linear_mfma_tile_kernel(ModulatorMfmaParams p) {
+    __shared__ float red[4][16 * RT][16 * FT + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * (16 * RT), f0 = blockIdx.y * (16 * FT);
+    const int nrows = p.count ? *p.count : p.B;
+    if (r0 >= nrows) return;  // workgroup-uniform
+    const int kq = lane >> 4;
+    const int K = p.Kh + p.Z;
+    const int nb = K / 16;
+    const int b_lo = (nb * wave) / 4, b_hi = (nb * (wave + 1)) / 4;
+    // per-lane row bases as 32-bit element offsets from the (uniform) operand pointers; rows / features past the end are
+    // clamped (computed, not stored)
+    unsigned wo[FT], ho[RT], zo[RT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) wo[ft] = (unsigned)min(f0 + 16 * ft + (lane & 15), p.H - 1) * (unsigned)K + 4u * kq;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const unsigned row = (unsigned)min(r0 + 16 * rt + (lane & 15), nrows - 1);
+        ho[rt] = row * (unsigned)p.H + 4u * kq;
+        zo[rt] = row * (unsigned)p.Z + 4u * kq;
+    }
+    mod_f32x4 acc0[RT][FT], acc1[RT][FT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) acc0[rt][ft] = acc1[rt][ft] = mod_f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int blk, mod_f32x4 (&a)[RT], mod_f32x4 (&b)[FT]) {
+        const int k0 = blk * 16;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+            a[rt] = *reinterpret_cast<const mod_f32x4*>(k0 < p.Kh ? p.hprev + ho[rt] + k0 : p.z + zo[rt] + (k0 - p.Kh));
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) b[ft] = *reinterpret_cast<const mod_f32x4*>(p.w + wo[ft] + k0);
+    };
+    auto mac = [&](const mod_f32x4 (&a)[RT], const mod_f32x4 (&b)[FT]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) {
+                acc0[rt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][0], b[ft][0], acc0[rt][ft], 0, 0, 0);
+                acc1[rt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][1], b[ft][1], acc1[rt][ft], 0, 0, 0);
+                acc0[rt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][2], b[ft][2], acc0[rt][ft], 0, 0, 0);
+                acc1[rt][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][3], b[ft][3], acc1[rt][ft], 0, 0, 0);
+            }
+    };
+    // two register stages: the fragments of block k + 1 are in flight while block k's 4 RT FT MFMAs run
+    mod_f32x4 a0[RT], b0[FT], a1[RT], b1[FT];
+    int blk = b_lo;
+    if (blk < b_hi) fetch(blk, a0, b0);
+    for (; blk + 2 <= b_hi; blk += 2) {
+        fetch(blk + 1, a1, b1);
+        mac(a0, b0);
+        if (blk + 2 < b_hi) fetch(blk + 2, a0, b0);
+        mac(a1, b1);
+    }
+    if (blk < b_hi) mac(a0, b0);
+    // D layout: col = lane & 15 (feature), row = 4 * (lane >> 4) + reg (patch)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][16 * rt + 4 * kq + r][16 * ft + (lane & 15)] = acc0[rt][ft][r] + acc1[rt][ft][r];
+    __syncthreads();
+    for (int i = tid; i < 16 * RT * 16 * FT; i += 256) {
+        const int rr = i / (16 * FT), cc = i - rr * (16 * FT);
+        if (r0 + rr < nrows && f0 + cc < p.H) {
+            const float s = red[0][rr][cc] + red[1][rr][cc] + red[2][rr][cc] + red[3][rr][cc] + p.bias[f0 + cc];
+            const float neg = p.act == LIN_ACT_RELU ? 0.f : (p.act == LIN_ACT_LEAKY02 ? 0.2f * s : s);
+            p.out[(size_t)(r0 + rr) * p.H + f0 + cc] = s <= 0.f ? neg : s;  // NaN stays NaN, as torch's activations
+        }
+    }
+}
+
 }  // namespace msiren

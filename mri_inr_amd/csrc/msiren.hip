@@ -23,11 +23,9 @@
 
 #include "../../include/msiren.h"
 #include "encoder_modulator.hip.h"
-#include "modulator_chain.hip.h"
 #include "mfma_probe.hip.h"
 #include "pass_queue.h"
 #include "weights_blob.h"
-#include "siren_trunk_f16x3.hip.h"
 #include "siren_trunk_f16x3n.hip.h"
 #include "siren_trunk_f16x3h.hip.h"
 #include "siren_trunk_f16x3w.hip.h"
@@ -72,12 +70,20 @@ struct msiren_ctx {
     struct StreamCtx {
         hipStream_t s = nullptr;
         DevBuf mods, modpad, latent, patches, keep, rec, queue, feat, plan;
-        DevBuf gran;  // modulator chain: stage outputs as {value, epoch} granules (zeroed when allocated)
+        DevBuf mods2;  // a split call's second part: modulations written on the OTHER stream, read by this stream's trunk
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // split call: start of the call -> helper stream; helper's prologue -> this stream
         msiren::PassQueue pq;  // host view of the never-reset pass counter (pass_queue.h)
     } sc[2];
     int cur = 0, nstreams = 1;
     bool overlap = false;  // a host-pointer call is pipelining itself over both streams
     bool solo = false;     // a synchronous host-pointer call is running on ONE stream: nothing of this handle is to run beside its trunk
+    // which split-fp16 trunk a launch takes: 0 = launch_trunk_f16x3's own rule; 1 = register-resident with room beside it
+    // (ring of 3); 2 = weight-stationary.  Set by forward_tiles_split around its two trunk launches.
+    int trunk_force = 0;
+    int64_t split_min = 3200;  // MSIREN_SPLIT_MIN: *_dev forward calls of at least this many tiles are cut in two (0 = never)
+    int split_pct = 12;        // MSIREN_SPLIT_PCT: share of the first part, percent
+    int lin_tile_min = 1024;   // MSIREN_LINEAR_TILE_MIN: rows from which the Linear layers use the 32 x 32-tile kernel (0 = never)
+    char last_trunk[96] = "";  // name of the trunk instance launched last (msiren_last_trunk_kernel)
     const int* plan = nullptr;  // device-side list of non-black patches in effect (slice pipeline only)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, std::vector<float>> tensors;  // state_dict, host copies
@@ -88,9 +94,7 @@ struct msiren_ctx {
     float *d_grid = nullptr, *d_l0 = nullptr, *d_wp = nullptr, *d_bias = nullptr, *d_wout = nullptr;
     float bout = 0.f, cg0 = 0.f, cg = 0.f;
     // split-fp16 trunk (MSIREN_PREC_F16X3)
-    void* d_wp16 = nullptr;   // weight stream of the 32x32x16 kernel (A/B reference, MSIREN_F16_TILE=32)
     void* d_wp16n = nullptr;  // weight stream of the 16x16x32 kernel (default)
-    int f16_tile = 16;        // MFMA tile of the split-fp16 trunk in use
     int lds_attr_f16n[2][4] = {};
     int lds_attr_f16h[2][2] = {};  // half-unit instances (num_layers = 5 only)
     int lds_attr_f16w[2] = {};     // weight-stationary instances ([activation])
@@ -101,18 +105,10 @@ struct msiren_ctx {
     bool f16_off = false;          // the call in flight is the exact-fp32 re-run of a host-pointer call
     int64_t range_events = 0;      // launches that raised the flag (re-run or reported) since create
     float* d_dump = nullptr;       // 256 floats: where lanes of the weight-stationary trunk that have nothing to store write
-    // modulator chain (modulator_chain.hip.h): conv3, Linear(64, Z) and the Modulator layers in one launch, single-stream handles
-    int chain_on = 0;              // MSIREN_CHAIN=1: on (read at create).  Off by default: measured no faster than a launch per layer
     int trace_host = 0;            // MSIREN_TRACE_HOST=1: msiren_forward_tiles prints the host-side timeline of the call (stderr)
     int host_first_pct = 50;       // MSIREN_HOST_SPLIT: share (percent) of the batch in the first of the two chunks of a host call
-    int chain_clusters = 0;
-    unsigned chain_spin = 400000;  // MSIREN_CHAIN_SPIN (tests: 0 = give up at the first poll that finds the stage unfinished)
-    bool chain_rerun_pending = false;
-    unsigned long long* chain_stamps = nullptr;  // set for the one launch of msiren_chain_timeline
-    int64_t chain_events = 0;      // launches that gave up a hand-off wait (chain switched off for the handle afterwards)
     int f16_ws = 1;                // the weight-stationary trunk runs single-stream launches (MSIREN_F16_WS=0: never; read at create)
     float *d_bias16 = nullptr, *d_wout16 = nullptr, *d_s0t = nullptr;
-    float winv16[16] = {0};    // 32x32 kernel: exact inverse of each hidden layer's power-of-two weight scale
     float mscale16[16] = {0};  // 16x16 kernel: factor of each layer's modulation row (the NEXT layer's weight scale, inverted)
     bool f16x3_ready = false;
     // single-product 16-bit trunk (MSIREN_PREC_BF16 / MSIREN_PREC_F16), H = 512
@@ -127,7 +123,6 @@ struct msiren_ctx {
     int half_allowed = 1;      // MSIREN_F16_HALF=0: never use the half-unit instance
     int host_chunks = 0;       // MSIREN_HOST_CHUNKS: chunks a synchronous host call cuts itself into (0 = default)
     unsigned queue_start = 0;  // MSIREN_QUEUE_START: initial value of the never-reset pass counters
-    int lds_attr_f16[2][2] = {};  // dynamic-LDS limit already raised for siren_trunk_f16x3_kernel<act, R> ([R == 4][act])
     // modulator: transposed weights so that consecutive threads read consecutive outputs
     float *d_modw = nullptr, *d_modb = nullptr, *d_modw_rm = nullptr;  // transposed / as stored (row-major)
     // encoder
@@ -140,7 +135,10 @@ struct msiren_ctx {
     bool profile = false;
     int64_t prof_launches = 0;
     double prof_ms = 0.0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    struct ProfRec { hipEvent_t a, b; int kernel; int64_t coords; };
+    struct ProfKernel { std::string name; int64_t launches = 0, coords = 0; double ms = 0.0; };
+    std::vector<ProfRec> prof_events;
+    std::vector<ProfKernel> prof_kernels;  // totals per trunk instance since msiren_profile_enable(h, 1), in order of first launch
     size_t prof_used = 0;
     // multi-GPU: RCCL communicator this handle is a rank of (msiren_comm_*), staging buffer of its collectives
     ncclComm_t comm = nullptr;
@@ -310,35 +308,12 @@ int pack_trunk_f16x3(msiren_ctx* h) {
     if (h->cfg.precision != MSIREN_PREC_F16X3 || H != 256 || L < 2 || msiren::F16Lds<3>::total(L) > 160 * 1024) return 0;
     const double two_pi = 6.283185307179586476925286766559;
     const double c = (double)h->cfg.w0 / two_pi;
-#ifdef MSIREN_WITH_TILE32
-    std::vector<uint16_t> wp((size_t)(L - 1) * 8 * 16 * 2 * 64 * 8);  // stream of the 32x32x16 kernel (A/B builds only)
-#endif
     std::vector<uint16_t> wpn((size_t)(L - 1) * 8 * 16 * 2 * 64 * 8);
     std::vector<float> bias((size_t)(L - 1) * 256, 0.f), wout(256, 0.f);
     for (int l = 1; l < L; ++l) {
         const std::vector<float>& w = *get(h, "net.layers." + std::to_string(l) + ".weight");
         double mx = 0.0;
         for (float v : w) mx = std::max(mx, std::fabs((double)v * c));
-        int e = 0;
-        if (mx > 0.0) e = (int)std::floor(std::log2(16384.0 / mx));
-        e = std::max(-14, std::min(e, 30));
-        h->winv16[l - 1] = (float)std::ldexp(1.0, -e);
-#ifdef MSIREN_WITH_TILE32
-        const double sc = std::ldexp(c, e);
-        for (int t = 0; t < 8; ++t)
-            for (int s = 0; s < 16; ++s)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int f = 32 * t + (lane & 31);
-                        const int k = 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-                        const float ws = (float)((double)w[(size_t)f * H + k] * sc);
-                        const uint16_t hi = f32_to_f16_rne(ws);
-                        const uint16_t lo = f32_to_f16_rne(ws - f16_to_f32(hi));
-                        const size_t base = ((((size_t)(l - 1) * 8 + t) * 16 + s) * 2) * 64 * 8;
-                        wp[base + (size_t)lane * 8 + j] = hi;
-                        wp[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
-                    }
-#endif
         // 16x16x32 kernel (siren_trunk_f16x3n.hip.h): chunk (l, t) = [8 k-steps][2 sub-tiles][hi|lo][64 lanes][8 x f16];
         // lane (r = lane & 15, q = lane >> 4), element j of k-step s of sub-tile u: output feature 32 t + 16 u + r,
         // input feature 32 s + 16 (j >> 2) + 4 q + (j & 3).  Scale 2^a with rms|W'| ~ 0.1 (a is undone on the
@@ -374,20 +349,10 @@ int pack_trunk_f16x3(msiren_ctx* h) {
     h->mscale16[L - 1] = 1.0f;  // the last hidden layer's output meets last_layer unscaled
     const auto* Wo = get(h, "net.last_layer.weight");
     for (int f = 0; f < H; ++f) wout[f] = (float)((double)(*Wo)[f] * c);
-#ifdef MSIREN_WITH_TILE32
-    if (h->d_wp16) HIPCHK(hipFree(h->d_wp16));
-    h->d_wp16 = nullptr;
-    HIPCHK(hipMalloc(&h->d_wp16, wp.size() * 2));
-    HIPCHK(hipMemcpy(h->d_wp16, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
-#endif
     if (h->d_wp16n) HIPCHK(hipFree(h->d_wp16n));
     h->d_wp16n = nullptr;
     HIPCHK(hipMalloc(&h->d_wp16n, wpn.size() * 2));
     HIPCHK(hipMemcpy(h->d_wp16n, wpn.data(), wpn.size() * 2, hipMemcpyHostToDevice));
-    h->f16_tile = 16;
-#ifdef MSIREN_WITH_TILE32
-    if (const char* e = std::getenv("MSIREN_F16_TILE")) h->f16_tile = std::atoi(e) == 32 ? 32 : 16;  // A/B knob
-#endif
     int rc;
     if ((rc = upload(&h->d_bias16, bias))) return rc;
     if ((rc = upload(&h->d_wout16, wout))) return rc;
@@ -610,6 +575,7 @@ int launch_trunk_hp(msiren_ctx* h, const msiren::TrunkParams& p, int grid) {
             done = (int)lds;                                                                       \
         }                                                                                          \
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);                           \
+        std::snprintf(h->last_trunk, sizeof h->last_trunk, "siren_trunk_f32_kernel<%d,%d,%d>", HP, A, R); \
     } while (0)
     if (act == MSIREN_ACT_MORLET) {
         if (res) MSIREN_LAUNCH(1, 1); else MSIREN_LAUNCH(1, 0);
@@ -677,33 +643,6 @@ int queue_reset_after_plan_launch(msiren_ctx* h) {
     return 0;
 }
 
-// The 32x32x16 kernel (siren_trunk_f16x3.hip.h) is the A/B reference of the 16x16x32 one: compiled in only with
-// -DMSIREN_WITH_TILE32 (make AB32=1), selected at run time with MSIREN_F16_TILE=32.
-#ifdef MSIREN_WITH_TILE32
-template <int R>
-int launch_trunk_f16x3_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int grid) {
-    const int lds = msiren::F16Lds<R>::total(h->L);
-    auto k0 = msiren::siren_trunk_f16x3_kernel<0, R>;
-    auto k1 = msiren::siren_trunk_f16x3_kernel<1, R>;
-    const bool mor = h->cfg.activation == MSIREN_ACT_MORLET;
-    const void* kp = mor ? (const void*)k1 : (const void*)k0;
-    // raise the dynamic-LDS limit once per handle and kernel instance (R, activation): handle-local state, so
-    // handles on different threads never share it
-    int& done = h->lds_attr_f16[R == 4 ? 1 : 0][mor ? 1 : 0];
-    if (done < lds) {
-        HIPCHK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        done = lds;
-    }
-    if (mor)
-        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
-    else
-        hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-#endif
-
 template <int R>
 int launch_trunk_f16x3n_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int grid) {
     const int lds = msiren::F16Lds<R>::total(h->L);
@@ -719,6 +658,7 @@ int launch_trunk_f16x3n_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int gr
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
     HIPCHK(hipGetLastError());
+    std::snprintf(h->last_trunk, sizeof h->last_trunk, "siren_trunk_f16x3n_kernel<%d,%d,%d>", mor ? 1 : 0, R, l5 ? 5 : 0);
     return 0;
 }
 
@@ -736,6 +676,7 @@ int launch_trunk_f16x3h_r(msiren_ctx* h, const msiren::TrunkF16Params& p, int gr
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
     HIPCHK(hipGetLastError());
+    std::snprintf(h->last_trunk, sizeof h->last_trunk, "siren_trunk_f16x3h_kernel<%d,%d,5>", mor ? 1 : 0, R);
     return 0;
 }
 
@@ -788,32 +729,35 @@ int launch_trunk_f16x3w(msiren_ctx* h, const float* mods_dev, int64_t B, float* 
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);
     hipError_t e = hipGetLastError();
+    std::snprintf(h->last_trunk, sizeof h->last_trunk, "siren_trunk_f16x3w_kernel<%d,4>", mor ? 1 : 0);
     return queue_launched(h, e == hipSuccess ? 0 : fail(MSIREN_E_HIP, "trunk launch: %s", hipGetErrorString(e)));
 }
 
 // The weight-stationary trunk is the faster kernel on its own (it owns the whole register file and LDS of its CUs, so
 // nothing can run beside it); with two streams the register-resident trunk wins because the next call's encoder and
 // modulator run beside it.  Depths 3..5 (its unit images + tables must fit the LDS); modulation buffer below 4 GB.
-bool use_f16x3w(msiren_ctx* h, int64_t B) {
-    return h->f16_ws && (h->nstreams == 1 || h->solo) && !h->overlap && h->L >= 3 && h->L <= 8 &&
-           msiren::WsLds<4>::total(h->L) <= 160 * 1024 && (int64_t)h->L * B * 256 * 4 < (1LL << 32);
+bool ws_capable(msiren_ctx* h, int64_t B) {
+    static_assert(msiren::WsLds<4>::total(msiren::WS_MAX_L) <= 160 * 1024, "unit images + tables of the deepest supported model must fit the LDS");
+    return h->f16_ws && h->L >= msiren::WS_MIN_L && h->L <= msiren::WS_MAX_L && (int64_t)h->L * B * 256 * 4 < (1LL << 32);
 }
+bool use_f16x3w(msiren_ctx* h, int64_t B) { return ws_capable(h, B) && (h->nstreams == 1 || h->solo) && !h->overlap; }
 
 int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     const int upp_ = (h->P + 31) / 32;
     // (small batches of depth-5 models keep the half-unit instance: twice the waves, lower latency)
-    if (use_f16x3w(h, B) && !(h->L == 5 && h->half_allowed && !h->plan && B * upp_ <= 2 * (int64_t)h->cus_limit))
+    if (h->trunk_force == 2 ||
+        (h->trunk_force == 0 && use_f16x3w(h, B) && !(h->L == 5 && h->half_allowed && !h->plan && B * upp_ <= 2 * (int64_t)h->cus_limit)))
         return launch_trunk_f16x3w(h, mods_dev, B, out_dev);
     msiren::TrunkF16Params p{};
     p.grid = h->d_grid;
     p.l0 = h->d_l0;
     p.s0t = h->d_s0t;
-    p.wp = (const _Float16*)(h->f16_tile == 16 ? h->d_wp16n : h->d_wp16);
+    p.wp = (const _Float16*)h->d_wp16n;
     p.bias = h->d_bias16;
     p.wout = h->d_wout16;
     p.mods = mods_dev;
     p.out = out_dev;
-    for (int i = 0; i < 16; ++i) p.winv[i] = h->f16_tile == 16 ? h->mscale16[i] : h->winv16[i];
+    for (int i = 0; i < 16; ++i) p.winv[i] = h->mscale16[i];
     p.bout = h->bout;
     p.cg0 = h->cg0;
     p.cg = h->cg;
@@ -827,7 +771,7 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     if (units > 0x3fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     // R = 3 leaves ~35 KB of LDS per CU free, enough for an encoder / modulator workgroup of the NEXT
     // call (other stream) to run beside the persistent trunk workgroup; R = 4 fills the CU.
-    int ring = ((h->nstreams > 1 && !h->solo) || h->overlap) ? 3 : 4;
+    int ring = ((h->nstreams > 1 && !h->solo) || h->overlap || h->trunk_force == 1) ? 3 : 4;
     // depths other than 5 run the loop form of the kernel: with a ring of 3 hipcc gives it all 512 registers (and 188 bytes of
     // scratch per lane), so nothing could run beside it anyway -- the ring of 4 has neither (164 + 240 registers)
     if (ring == 3 && h->L != 5) ring = 4;
@@ -845,9 +789,6 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
         const int grid = (int)std::min<int64_t>(cus, passes);
         int rc = queue_for_launch(h, passes, &p.pass_counter, &p.pass_base);
         if (rc) return rc;
-#ifdef MSIREN_WITH_TILE32
-        if (h->f16_tile == 32) return queue_launched(h, r4 ? launch_trunk_f16x3_r<4>(h, p, grid) : launch_trunk_f16x3_r<3>(h, p, grid));
-#endif
         if (half) return queue_launched(h, r4 ? launch_trunk_f16x3h_r<4>(h, p, grid) : launch_trunk_f16x3h_r<3>(h, p, grid));
         return queue_launched(h, r4 ? launch_trunk_f16x3n_r<4>(h, p, grid) : launch_trunk_f16x3n_r<3>(h, p, grid));
     };
@@ -861,7 +802,7 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     // stream (event fork / join, no launch gap): 0.315 vs 0.289 ms.  A half-unit pass on an otherwise idle chip is not
     // half a round (its weight-fragment reads are those of a full unit; prologue and layer 0 do not shrink), and the
     // cross-stream dependency costs more than the tail it removes.
-    const bool half_ok = h->f16_tile == 16 && !h->plan && h->L == 5 && h->half_allowed;
+    const bool half_ok = !h->plan && h->L == 5 && h->half_allowed;
     if (half_ok && units <= 2 * (int64_t)cus) return launch_piece(true, 0, B * ((h->P + 15) / 16));
     return launch_piece(false, 0, units);
 }
@@ -907,6 +848,7 @@ int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int gr
             h->lds_attr_x1 = lds;                                                                    \
         }                                                                                            \
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);                       \
+        std::snprintf(h->last_trunk, sizeof h->last_trunk, "siren_trunk_x1_kernel<%d,%d,%d,3>", BF, A, RS); \
     } while (0)
     if (bf) {
         if (mor) { if (res) MSIREN_X1_LAUNCH(1, 1, 1); else MSIREN_X1_LAUNCH(1, 1, 0); }
@@ -933,11 +875,28 @@ int profile_begin(msiren_ctx* h, hipEvent_t* end_event) {
         hipEvent_t a, b;
         HIPCHK(hipEventCreate(&a));
         HIPCHK(hipEventCreate(&b));
-        h->prof_events.emplace_back(a, b);
+        h->prof_events.push_back({a, b, -1, 0});
     }
-    HIPCHK(hipEventRecord(h->prof_events[h->prof_used].first, h->sc[h->cur].s));
-    *end_event = h->prof_events[h->prof_used].second;
+    HIPCHK(hipEventRecord(h->prof_events[h->prof_used].a, h->sc[h->cur].s));
+    *end_event = h->prof_events[h->prof_used].b;
     h->prof_used++;
+    return 0;
+}
+
+// closes the pair profile_begin opened: the launch in between was h->last_trunk over `coords` coordinates
+int profile_end(msiren_ctx* h, hipEvent_t end_event, int64_t coords) {
+    if (!end_event) return 0;
+    HIPCHK(hipEventRecord(end_event, h->sc[h->cur].s));
+    auto& r = h->prof_events[h->prof_used - 1];
+    int k = 0;
+    for (; k < (int)h->prof_kernels.size(); ++k)
+        if (h->prof_kernels[k].name == h->last_trunk) break;
+    if (k == (int)h->prof_kernels.size()) {
+        h->prof_kernels.emplace_back();
+        h->prof_kernels.back().name = h->last_trunk;
+    }
+    r.kernel = k;
+    r.coords = coords;
     return 0;
 }
 
@@ -951,8 +910,7 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
         }
         int rc = h->x1_ready ? launch_trunk_x1(h, mods_dev, B, out_dev) : launch_trunk_f16x3(h, mods_dev, B, out_dev);
         if (rc) return rc;
-        if (e1) HIPCHK(hipEventRecord(e1, h->sc[h->cur].s));
-        return 0;
+        return profile_end(h, e1, B * h->P);
     }
     const int chunks = (h->P + 63) / 64;
     if (B * (int64_t)chunks > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
@@ -982,100 +940,27 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
         default: return fail(MSIREN_E_INVALID, "dim_hidden=%d (padded %d) is not supported by the fp32 trunk (max 512)", h->H, h->HP);
     }
     if (rc) return rc;
-    if (e1) HIPCHK(hipEventRecord(e1, h->sc[h->cur].s));
-    return 0;
+    return profile_end(h, e1, B * h->P);
 }
 
-// ---- the Linear layers of encoder tail + modulator as one launch (modulator_chain.hip.h) -----------------------------
-// Single-stream handles only: the grid (<= one workgroup per CU) must be resident as a whole, which it is when the
-// stream's previous kernel has finished and no other stream of the handle is running a persistent trunk.
-size_t chain_lds_bytes(const msiren_ctx* h) { return (size_t)msiren::CHAIN_GPC * 16 * (h->Z + msiren::CHAIN_ZPAD) * sizeof(float); }
-
-bool use_chain(msiren_ctx* h, int64_t B) {
-    // H % 128: a batch of 8 k-blocks never straddles the [hidden ; latent] seam of a Modulator layer's input
-    return h->chain_on && h->chain_clusters > 0 && h->nstreams == 1 && !h->overlap && h->H % 128 == 0 &&
-           h->Z % 16 == 0 && h->L + 2 <= msiren::CHAIN_STAGES && chain_lds_bytes(h) <= 64 * 1024 &&
-           B <= (int64_t)h->chain_clusters * msiren::CHAIN_GPC * 16;  // larger batches are throughput-bound: a launch per layer fills the chip
-}
-
-// The exchange buffer of the stream: [conv3 out (B, 64)] [latent (B, Z)] [Modulator layers 0..L-2 (B, H) each], 8 bytes per
-// element.  Zeroed when (re)allocated: a granule is valid only under the launch's epoch, and epochs are never reused.
-std::atomic<unsigned> g_chain_epoch{0};
-
-int chain_exchange(msiren_ctx* h, int64_t B, unsigned long long** a3, unsigned long long** z, unsigned long long** hid) {
-    auto& c = h->sc[h->cur];
-    const size_t elems = (size_t)B * (64 + h->Z + (size_t)(h->L - 1) * h->H);
-    const void* before = c.gran.p;
-    int rc = ensure(h, c.gran, elems * 8);
-    if (rc) return rc;
-    if (c.gran.p != before) HIPCHK(hipMemsetAsync(c.gran.p, 0, c.gran.cap, c.s));
-    *a3 = (unsigned long long*)c.gran.p;
-    *z = *a3 + (size_t)B * 64;
-    *hid = *z + (size_t)B * h->Z;
-    return 0;
-}
-
-void chain_add_modulator_stages(msiren_ctx* h, msiren::ChainParams& cp, const float* z_dev, const unsigned long long* z_gran,
-                                unsigned long long* hid, int64_t B, float* mods_dev) {
-    size_t off = 0;
-    for (int l = 0; l < h->L; ++l) {
-        const int Kh = (l == 0 ? 0 : h->H);
-        msiren::ChainStage& st = cp.st[cp.nstages++];
-        st.w = h->d_modw_rm + off;
-        st.bias = h->d_modb + (size_t)l * h->H;
-        st.a = l == 0 ? nullptr : (const void*)(hid + (size_t)(l - 1) * B * h->H);
-        st.a_gran = 1;
-        st.b = z_gran ? (const void*)z_gran : (const void*)z_dev;
-        st.b_gran = z_gran ? 1 : 0;
-        st.b_lds = 1;
-        st.out = mods_dev + (size_t)l * B * h->H;
-        st.gout = l + 1 < h->L ? (void*)(hid + (size_t)l * B * h->H) : nullptr;  // the last layer's readers are in the next launch
-        st.H = h->H;
-        st.Ka = Kh;
-        st.Kb = h->Z;
-        st.act = msiren::LIN_ACT_RELU;
-        off += (size_t)(Kh + h->Z) * h->H;
+// One Linear layer over the batch on the matrix cores: 16 x 16 output tiles (latency sizes) or 32 x 32 (throughput sizes:
+// half the operand bytes per FLOP).  Same arithmetic either way -- an output does not depend on the batch it came in.
+int launch_linear(msiren_ctx* h, const msiren::ModulatorMfmaParams& mp) {
+    hipStream_t s = h->sc[h->cur].s;
+    if (h->lin_tile_min > 0 && mp.B >= h->lin_tile_min) {
+        dim3 grid((unsigned)((mp.B + 31) / 32), (unsigned)((mp.H + 31) / 32));
+        hipLaunchKernelGGL((msiren::linear_mfma_tile_kernel<2, 2>), grid, dim3(256), 0, s, mp);
+    } else {
+        dim3 grid((unsigned)((mp.B + 15) / 16), (unsigned)(mp.H / 16));
+        hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, grid, dim3(256), 0, s, mp);
     }
-}
-
-int launch_chain(msiren_ctx* h, msiren::ChainParams& cp, int64_t B) {
-    cp.B = (int)B;
-    const int groups = (int)((B + 15) / 16);
-    cp.gpc = (groups + h->chain_clusters - 1) / h->chain_clusters;
-    cp.count = h->plan;
-    cp.gave_up = h->status_dev + 1;
-    cp.spin_limit = h->chain_spin;  // sweeps (one round trip each): a few tenths of a second
-    cp.stamps = h->chain_stamps;
-    do cp.epoch = ++g_chain_epoch;
-    while (cp.epoch == 0);
-    hipLaunchKernelGGL(msiren::modulator_chain_kernel, dim3((unsigned)(h->chain_clusters * msiren::CHAIN_MEMBERS)), dim3(256),
-                       chain_lds_bytes(h), h->sc[h->cur].s, cp);
     HIPCHK(hipGetLastError());
     return 0;
-}
-
-// a chain launch gave up a wait (the flag is raised by the kernel): its outputs and everything computed from them are
-// not valid.  Chain off for this handle -- the per-layer launches take over.
-bool take_chain_flag(msiren_ctx* h) {
-    if (!h->status_host || !h->status_host[1]) return false;
-    h->status_host[1] = 0;
-    h->chain_events++;
-    h->chain_on = 0;
-    h->chain_rerun_pending = true;
-    return true;
 }
 
 int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_dev) {
     if (B == 0) return 0;
     if (!h->have_modulator) return fail(MSIREN_E_STATE, "modulator.* weights were not loaded");
-    if (use_chain(h, B)) {
-        msiren::ChainParams cp{};
-        unsigned long long *g_a3, *g_z, *g_hid;
-        int rc = chain_exchange(h, B, &g_a3, &g_z, &g_hid);
-        if (rc) return rc;
-        chain_add_modulator_stages(h, cp, z_dev, nullptr, g_hid, B, mods_dev);  // the latent is there before the launch: plain
-        return launch_chain(h, cp, B);
-    }
     size_t off = 0;
     const bool mfma_ok = (h->H % 16 == 0) && (h->Z % 16 == 0);
     for (int l = 0; l < h->L && mfma_ok; ++l) {
@@ -1092,9 +977,8 @@ int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_d
         mp.Kh = Kh;
         mp.act = msiren::LIN_ACT_RELU;
         mp.count = h->plan;
-        dim3 grid((unsigned)((B + 15) / 16), (unsigned)(h->H / 16));
-        hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, grid, dim3(256), 0, h->sc[h->cur].s, mp);
-        HIPCHK(hipGetLastError());
+        int rc = launch_linear(h, mp);
+        if (rc) return rc;
         off += (size_t)(Kh + h->Z) * h->H;
     }
     if (mfma_ok) return 0;
@@ -1150,8 +1034,7 @@ int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_de
     mp.Z = 2048;
     mp.act = msiren::LIN_ACT_LEAKY02;
     mp.count = h->plan;
-    hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, dim3((unsigned)((B + 15) / 16), 4), dim3(256), 0, s, mp);
-    HIPCHK(hipGetLastError());
+    if ((rc = launch_linear(h, mp))) return rc;
     mp.w = h->d_fcw_rm;
     mp.bias = h->enc.fcb;
     mp.z = a3;
@@ -1159,54 +1042,15 @@ int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_de
     mp.H = h->Z;
     mp.Z = 64;
     mp.act = msiren::LIN_ACT_NONE;
-    hipLaunchKernelGGL(msiren::modulator_layer_mfma_kernel, dim3((unsigned)((B + 15) / 16), (unsigned)(h->Z / 16)), dim3(256), 0, s, mp);
-    HIPCHK(hipGetLastError());
-    return 0;
+    return launch_linear(h, mp);
 }
 
-// encoder + modulator: tiles -> latent -> modulations.  With the chain: conv1+conv2 per tile, then ONE launch for
-// conv3, Linear(64, Z) and the Modulator layers (3 launches per forward with the trunk); small batches keep the fused
-// per-tile encoder and chain the Modulator layers only.
+// encoder + modulator: tiles -> latent -> modulations
 int launch_encoder_modulator(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_dev, float* mods_dev) {
     if (B == 0) return 0;
-    if (!(use_chain(h, B) && h->have_encoder && h->have_modulator && B >= 48)) {
-        int rc = launch_encoder(h, tiles_dev, B, z_dev);
-        if (rc) return rc;
-        return launch_modulator(h, z_dev, B, mods_dev);
-    }
-    auto& c = h->sc[h->cur];
-    int rc = ensure(h, c.feat, (size_t)B * (2048 + 64) * sizeof(float));
+    int rc = launch_encoder(h, tiles_dev, B, z_dev);
     if (rc) return rc;
-    float* feat = (float*)c.feat.p;
-    float* a3 = feat + (size_t)B * 2048;
-    h->enc.plan = h->plan;
-    hipLaunchKernelGGL(msiren::encoder_conv_kernel, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, feat);
-    HIPCHK(hipGetLastError());
-    msiren::ChainParams cp{};
-    unsigned long long *g_a3, *g_z, *g_hid;
-    rc = chain_exchange(h, B, &g_a3, &g_z, &g_hid);
-    if (rc) return rc;
-    msiren::ChainStage& c3 = cp.st[cp.nstages++];
-    c3.w = h->d_c3w_rm;
-    c3.bias = h->enc.c3b;
-    c3.b = feat;
-    c3.out = a3;
-    c3.gout = g_a3;
-    c3.H = 64;
-    c3.Kb = 2048;
-    c3.act = msiren::LIN_ACT_LEAKY02;
-    msiren::ChainStage& fc = cp.st[cp.nstages++];
-    fc.w = h->d_fcw_rm;
-    fc.bias = h->enc.fcb;
-    fc.b = g_a3;
-    fc.b_gran = 1;
-    fc.out = z_dev;
-    fc.gout = g_z;
-    fc.H = h->Z;
-    fc.Kb = 64;
-    fc.act = msiren::LIN_ACT_NONE;
-    chain_add_modulator_stages(h, cp, z_dev, g_z, g_hid, B, mods_dev);
-    return launch_chain(h, cp, B);
+    return launch_modulator(h, z_dev, B, mods_dev);
 }
 
 int forward_latent_dev(msiren_ctx* h, const float* z_dev, int64_t B, float* out_dev, float* mods_out_dev) {
@@ -1221,7 +1065,57 @@ int forward_latent_dev(msiren_ctx* h, const float* z_dev, int64_t B, float* out_
     return launch_trunk(h, mods, B, out_dev);
 }
 
+// ---- large calls: hide the encoder + modulator of most of the batch behind the trunk of its first part ----------------
+// One big call cannot overlap with itself: its prologue (conv1/conv2, conv3, Linear, L Modulator layers -- 20 us per
+// 400 tiles at throughput sizes) ran in front of a trunk that then had the chip to itself: 1.3 of 17.2 ms for 64 slices.
+// The weight-stationary trunk leaves no room beside it, the register-resident one does.  So a call of
+// >= split_min tiles is cut in two:
+//     call's stream:   E0 | prologue(part 0) | register-resident trunk(part 0) | wait E1 | weight-stationary trunk(part 1)
+//     other stream:    wait E0 | prologue(part 1) ........................... E1
+// part 0 (split_pct of the batch) is sized so that its trunk outlasts part 1's prologue running beside it.  Patches are
+// independent and both trunks give the same bits (tests/test_gpu_ws.py), so the cut does not change results.  The
+// modulations of part 1 cross streams (mods2 of the call's stream, written on the other one); latent and conv features
+// stay on the stream that produces and consumes them.  The call still "happens on its stream": inputs are read and
+// outputs written by work that the stream's tail depends on.
+bool use_split(msiren_ctx* h, int64_t B) {
+    return h->split_min > 0 && B >= h->split_min && (h->nstreams == 1 || h->solo) && !h->plan && !h->overlap && !h->f16_off && h->L == 5 && use_f16x3(h) &&
+           !h->x1_ready && h->have_encoder && h->have_modulator && h->Z % 16 == 0 && ws_capable(h, B);
+}
+
+int forward_tiles_split(msiren_ctx* h, const float* tiles_dev, int64_t B, float* out_dev) {
+    const int a = h->cur, b = a ^ 1;
+    auto& A = h->sc[a];
+    auto& O = h->sc[b];
+    int64_t B0 = (B * h->split_pct / 100 + 15) / 16 * 16;
+    B0 = std::max<int64_t>(16, std::min<int64_t>(B0, B - 16));
+    const int64_t B1 = B - B0;
+    int rc;
+    if ((rc = ensure(h, A.latent, (size_t)B0 * h->Z * sizeof(float))) || (rc = ensure(h, A.mods, (size_t)h->L * B0 * h->H * sizeof(float))) ||
+        (rc = ensure(h, O.latent, (size_t)B1 * h->Z * sizeof(float))) || (rc = ensure(h, A.mods2, (size_t)h->L * B1 * h->H * sizeof(float))))
+        return rc;
+    if (!A.ev_fork) HIPCHK(hipEventCreateWithFlags(&A.ev_fork, hipEventDisableTiming));
+    if (!A.ev_join) HIPCHK(hipEventCreateWithFlags(&A.ev_join, hipEventDisableTiming));
+    struct Restore {  // the launchers below address the stream through h->cur and the trunk through h->trunk_force
+        msiren_ctx* h;
+        int cur;
+        ~Restore() { h->cur = cur; h->trunk_force = 0; }
+    } restore{h, a};
+    HIPCHK(hipEventRecord(A.ev_fork, A.s));
+    HIPCHK(hipStreamWaitEvent(O.s, A.ev_fork, 0));
+    h->cur = b;  // part 1's prologue first: it is the long one, and nothing it needs is still to come
+    if ((rc = launch_encoder_modulator(h, tiles_dev + (size_t)B0 * h->O * h->O, B1, (float*)O.latent.p, (float*)A.mods2.p))) return rc;
+    HIPCHK(hipEventRecord(A.ev_join, O.s));
+    h->cur = a;
+    if ((rc = launch_encoder_modulator(h, tiles_dev, B0, (float*)A.latent.p, (float*)A.mods.p))) return rc;
+    h->trunk_force = 1;
+    if ((rc = launch_trunk(h, (const float*)A.mods.p, B0, out_dev))) return rc;
+    HIPCHK(hipStreamWaitEvent(A.s, A.ev_join, 0));
+    h->trunk_force = 2;
+    return launch_trunk(h, (const float*)A.mods2.p, B1, out_dev + (size_t)B0 * h->P);
+}
+
 int forward_tiles_dev(msiren_ctx* h, const float* tiles_dev, int64_t B, float* out_dev) {
+    if (use_split(h, B)) return forward_tiles_split(h, tiles_dev, B, out_dev);
     int rc = ensure(h, h->sc[h->cur].latent, (size_t)B * h->Z * sizeof(float));
     if (rc) return rc;
     rc = ensure(h, h->sc[h->cur].mods, (size_t)h->L * B * h->H * sizeof(float));
@@ -1243,10 +1137,6 @@ bool take_range_flag(msiren_ctx* h) {
 int sync_all(msiren_ctx* h) {
     for (auto& c : h->sc)
         if (c.s) HIPCHK(hipStreamSynchronize(c.s));
-    if (take_chain_flag(h))
-        return fail(MSIREN_E_HIP, "the modulator chain launch gave up waiting for a hand-off between its workgroups (its grid was not "
-                                  "resident as a whole: is another process holding CUs of this device?): the outputs of the calls since the "
-                                  "last sync are not valid.  The handle now uses one launch per layer; re-issue the calls");
     if (!h->f16_off && take_range_flag(h))
         return fail(MSIREN_E_RANGE, "a modulation (times the layer's power-of-two weight scale) exceeds what the split-fp16 trunk's fp16 "
                                     "operands can carry (65504), or is not finite: the outputs of the calls since the last sync are not valid. "
@@ -1260,10 +1150,6 @@ int sync_all(msiren_ctx* h) {
 template <typename F>
 int with_range_fallback(msiren_ctx* h, F&& run) {
     int rc = run();
-    if (rc == MSIREN_E_HIP && h->chain_events && !h->chain_on && h->chain_rerun_pending) {  // the chain gave up: per-layer launches now
-        h->chain_rerun_pending = false;
-        rc = run();
-    }
     if (rc == MSIREN_E_RANGE || (rc == 0 && take_range_flag(h))) {
         h->f16_off = true;
         rc = run();
@@ -1276,6 +1162,24 @@ int with_range_fallback(msiren_ctx* h, F&& run) {
 // asynchronous forward entry points rotate over the configured streams
 void next_stream(msiren_ctx* h) {
     if (h->nstreams > 1) h->cur ^= 1;
+}
+
+// event pairs recorded since the last collection -> totals (the streams have been synchronised by the caller)
+int profile_collect(msiren_ctx* h) {
+    for (size_t i = 0; i < h->prof_used; ++i) {
+        const auto& r = h->prof_events[i];
+        if (r.kernel < 0) continue;  // (the launch between the pair failed)
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        h->prof_ms += ms;
+        h->prof_launches++;
+        auto& k = h->prof_kernels[r.kernel];
+        k.ms += ms;
+        k.launches++;
+        k.coords += r.coords;
+    }
+    h->prof_used = 0;
+    return 0;
 }
 
 int check(msiren_ctx* h, bool need_commit = true) {
@@ -1431,18 +1335,18 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_HOST_CHUNKS")) h->host_chunks = std::max(1, std::min(std::atoi(e), 16));
     if (const char* e = std::getenv("MSIREN_QUEUE_START")) h->queue_start = (unsigned)std::strtoul(e, nullptr, 0);
     if (const char* e = std::getenv("MSIREN_F16_WS")) h->f16_ws = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_CHAIN")) h->chain_on = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_SPLIT_MIN")) h->split_min = std::max<long long>(0, std::atoll(e));
+    if (const char* e = std::getenv("MSIREN_LINEAR_TILE_MIN")) h->lin_tile_min = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("MSIREN_SPLIT_PCT")) h->split_pct = std::max(1, std::min(90, std::atoi(e)));
     if (const char* e = std::getenv("MSIREN_TRACE_HOST")) h->trace_host = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_HOST_SPLIT")) h->host_first_pct = std::max(5, std::min(95, std::atoi(e)));
-    if (const char* e = std::getenv("MSIREN_CHAIN_SPIN")) h->chain_spin = (unsigned)std::strtoul(e, nullptr, 0);
-    h->chain_clusters = std::min(16, h->cus_limit / msiren::CHAIN_MEMBERS);  // at most one workgroup per CU: the whole grid is resident
     declare_expected(h);
     hipError_t e = hipSetDevice(cfg->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->sc[0].s, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->sc[1].s, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->status_host, 64, hipHostMallocMapped);
     if (e == hipSuccess) {
-        h->status_host[0] = h->status_host[1] = 0;  // [0] f16x3 domain guard, [1] modulator chain gave up a wait
+        h->status_host[0] = h->status_host[1] = 0;  // [0] f16x3 domain guard
         e = hipHostGetDevicePointer((void**)&h->status_dev, (void*)h->status_host, 0);
     }
 
@@ -1464,21 +1368,24 @@ int msiren_destroy(msiren_handle h) {
     if (h->comm) (void)msiren_comm_destroy(h);
     if (h->status_host) (void)hipHostFree((void*)h->status_host);
     if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
-    if (h->d_wp16) (void)hipFree(h->d_wp16);
     if (h->d_wp16n) (void)hipFree(h->d_wp16n);
     for (void* q : {h->d_wpx1, h->d_biasx1, h->d_woutx1})
         if (q) (void)hipFree(q);
     float* ptrs[] = {h->d_dump, h->d_l0last, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
-    DevBuf* bufs[] = {&h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
+    DevBuf* bufs[] = {&h->sc[0].mods2, &h->sc[1].mods2, &h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
                       &h->sc[0].patches, &h->sc[0].keep, &h->sc[0].rec, &h->sc[1].mods, &h->sc[1].modpad, &h->sc[1].latent,
-                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec, &h->sc[0].queue, &h->sc[1].queue, &h->sc[0].feat, &h->sc[1].feat, &h->sc[0].plan, &h->sc[1].plan, &h->sc[0].gran, &h->sc[1].gran};
+                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec, &h->sc[0].queue, &h->sc[1].queue, &h->sc[0].feat, &h->sc[1].feat, &h->sc[0].plan, &h->sc[1].plan};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& pr : h->prof_events) {
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
+        (void)hipEventDestroy(pr.a);
+        (void)hipEventDestroy(pr.b);
+    }
+    for (auto& c : h->sc) {
+        if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
+        if (c.ev_join) (void)hipEventDestroy(c.ev_join);
     }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1640,10 +1547,6 @@ int msiren_modulate(msiren_handle h, const float* z_host, int64_t B, float* mods
     if ((rc = launch_modulator(h, (const float*)c.latent.p, B, (float*)c.mods.p))) return rc;
     HIPCHK(hipMemcpyAsync(mods_host, c.mods.p, nm, hipMemcpyDeviceToHost, c.s));
     HIPCHK(hipStreamSynchronize(c.s));
-    if (take_chain_flag(h)) {  // (opt-in one-launch form gave up: run the layers as launches)
-        h->chain_rerun_pending = false;
-        return msiren_modulate(h, z_host, B, mods_host);
-    }
     return 0;
 }
 
@@ -1985,6 +1888,7 @@ int msiren_profile_enable(msiren_handle h, int32_t on) {
     h->prof_used = 0;
     h->prof_launches = 0;
     h->prof_ms = 0.0;
+    h->prof_kernels.clear();
     return 0;
 }
 
@@ -1992,15 +1896,31 @@ int msiren_profile_read(msiren_handle h, int64_t* launches, double* trunk_ms_tot
     int rc = check(h, false);
     if (rc) return rc;
     if ((rc = sync_all(h))) return rc;
-    for (size_t i = 0; i < h->prof_used; ++i) {
-        float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, h->prof_events[i].first, h->prof_events[i].second));
-        h->prof_ms += ms;
-        h->prof_launches++;
-    }
-    h->prof_used = 0;
+    if ((rc = profile_collect(h))) return rc;
     if (launches) *launches = h->prof_launches;
     if (trunk_ms_total) *trunk_ms_total = h->prof_ms;
+    return 0;
+}
+
+int msiren_profile_read_kernel(msiren_handle h, int32_t index, char* name128, int64_t* launches, double* ms_total, int64_t* coords_total) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if ((rc = sync_all(h))) return rc;
+    if ((rc = profile_collect(h))) return rc;
+    if (index < 0 || index >= (int32_t)h->prof_kernels.size())
+        return fail(MSIREN_E_INVALID, "profile: %d trunk instance(s) were launched since msiren_profile_enable, index %d asked for",
+                    (int)h->prof_kernels.size(), index);
+    const auto& k = h->prof_kernels[index];
+    if (name128) std::snprintf(name128, 128, "%s", k.name.c_str());
+    if (launches) *launches = k.launches;
+    if (ms_total) *ms_total = k.ms;
+    if (coords_total) *coords_total = k.coords;
+    return 0;
+}
+
+int msiren_last_trunk_kernel(msiren_handle h, char* name128) {
+    if (!h || !name128) return fail(MSIREN_E_INVALID, "null argument");
+    std::snprintf(name128, 128, "%s", h->last_trunk);
     return 0;
 }
 
@@ -2044,9 +1964,9 @@ int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, flo
     if (rc) return rc;
     if (!h->f16x3_ready || h->cfg.activation != MSIREN_ACT_SINE) return fail(MSIREN_E_INVALID, "f16x3 timeline: H=256 sine model required");
     msiren::TrunkF16Params p{};
-    p.grid = h->d_grid; p.l0 = h->d_l0; p.s0t = h->d_s0t; p.wp = (const _Float16*)(h->f16_tile == 16 ? h->d_wp16n : h->d_wp16); p.bias = h->d_bias16;
+    p.grid = h->d_grid; p.l0 = h->d_l0; p.s0t = h->d_s0t; p.wp = (const _Float16*)h->d_wp16n; p.bias = h->d_bias16;
     p.wout = h->d_wout16; p.mods = mods_dev; p.out = out_dev;
-    for (int i = 0; i < 16; ++i) p.winv[i] = h->f16_tile == 16 ? h->mscale16[i] : h->winv16[i];
+    for (int i = 0; i < 16; ++i) p.winv[i] = h->mscale16[i];
     p.bout = h->bout; p.cg0 = h->cg0; p.cg = h->cg; p.B = (int)B; p.P = h->P; p.L = h->L;
     p.units_per_patch = (h->P + 31) / 32;
     p.total_units = (int)(B * p.units_per_patch);
@@ -2060,13 +1980,6 @@ int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, flo
     p.pass_base = 0;
     p.stamps = (unsigned long long*)st.p;
     const int lds = msiren::F16Lds<4>::total(h->L);
-#ifdef MSIREN_WITH_TILE32
-    if (h->f16_tile == 32) {
-        auto k = msiren::siren_trunk_f16x3_kernel<0, 4, 1>;
-        HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
-    } else
-#endif
     {
         if (h->L != 5) return fail(MSIREN_E_INVALID, "f16x3 timeline: the stamped build is the num_layers = 5 instance");
         auto k = msiren::siren_trunk_f16x3n_kernel<0, 4, 5, 1>;
@@ -2084,8 +1997,8 @@ int msiren_f16x3_timeline(msiren_handle h, const float* mods_dev, int64_t B, flo
 int msiren_f16x3w_timeline(msiren_handle h, const float* mods_dev, int64_t B, float* out_dev, uint64_t* stamps_host) {
     int rc = check(h);
     if (rc) return rc;
-    if (!h->f16x3_ready || h->cfg.activation != MSIREN_ACT_SINE || h->L < 3 || msiren::WsLds<4>::total(h->L) > 160 * 1024)
-        return fail(MSIREN_E_INVALID, "f16x3w timeline: H=256 sine model with 3 <= num_layers <= 5 required");
+    if (!h->f16x3_ready || h->cfg.activation != MSIREN_ACT_SINE || h->L < msiren::WS_MIN_L || h->L > msiren::WS_MAX_L)
+        return fail(MSIREN_E_INVALID, "f16x3w timeline: H=256 sine model with %d <= num_layers <= %d required", msiren::WS_MIN_L, msiren::WS_MAX_L);
     if (B <= 0 || !mods_dev || !out_dev || !stamps_host) return fail(MSIREN_E_INVALID, "bad arguments");
     msiren::TrunkWsParams p{};
     if (!h->d_dump) HIPCHK(hipMalloc((void**)&h->d_dump, 256 * sizeof(float)));
@@ -2102,6 +2015,10 @@ int msiren_f16x3w_timeline(msiren_handle h, const float* mods_dev, int64_t B, fl
     p.div_m = (unsigned)(((1ULL << p.div_k) + (unsigned)upp - 1) / (unsigned)upp);
     const int grid = (int)std::min<int64_t>(h->cus_limit, ((int64_t)p.total_units + 1) / 2);
     DevBuf st, q;
+    struct Free {  // whichever way the function is left
+        DevBuf &a, &b;
+        ~Free() { if (a.p) (void)hipFree(a.p); if (b.p) (void)hipFree(b.p); }
+    } free_on_exit{st, q};
     const size_t nst = (size_t)grid * 96 * 8 * sizeof(uint64_t);
     if ((rc = ensure(h, st, nst)) || (rc = ensure(h, q, 256))) return rc;
     hipStream_t s = h->sc[h->cur].s;
@@ -2117,8 +2034,6 @@ int msiren_f16x3w_timeline(msiren_handle h, const float* mods_dev, int64_t B, fl
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(stamps_host, st.p, nst, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipFree(st.p));
-    HIPCHK(hipFree(q.p));
     return 0;
 }
 
@@ -2338,35 +2253,6 @@ int msiren_mfma_sustained_probe(msiren_handle h, double* tflops, double* mhz_equ
     if (mhz_equivalent) *mhz_equivalent = (double)iters * 24 * 16.0 / (ms * 1e-3) * 1e-6;  // the clock at which one MFMA per 16 cycles gives this rate
     (void)hipFree(src.p);
     (void)hipFree(sink.p);
-    return 0;
-}
-
-int msiren_chain_timeline(msiren_handle h, const float* tiles_dev, int64_t B, float* out_dev, uint64_t* stamps_host) {
-    int rc = check(h);
-    if (rc) return rc;
-    if (B <= 0 || !tiles_dev || !out_dev || !stamps_host) return fail(MSIREN_E_INVALID, "bad arguments");
-    if (!use_chain(h, B)) return fail(MSIREN_E_INVALID, "chain timeline: the handle does not use the modulator chain (two streams, MSIREN_CHAIN=0, shape)");
-    const size_t nst = (size_t)h->chain_clusters * msiren::CHAIN_MEMBERS * (msiren::CHAIN_STAGES + 1) * sizeof(uint64_t);
-    DevBuf st;
-    if ((rc = ensure(h, st, nst))) return rc;
-    hipStream_t s = h->sc[h->cur].s;
-    HIPCHK(hipMemsetAsync(st.p, 0, nst, s));
-    h->chain_stamps = (unsigned long long*)st.p;
-    rc = forward_tiles_dev(h, tiles_dev, B, out_dev);
-    h->chain_stamps = nullptr;
-    if (!rc) {
-        HIPCHK(hipMemcpyAsync(stamps_host, st.p, nst, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-    }
-    (void)hipStreamSynchronize(s);
-    HIPCHK(hipFree(st.p));
-    return rc;
-}
-
-int msiren_chain_info(msiren_handle h, int32_t* active, int64_t* events) {
-    if (!h || !active || !events) return fail(MSIREN_E_INVALID, "null argument");
-    *active = (h->chain_on && h->chain_clusters > 0 && h->nstreams == 1) ? 1 : 0;
-    *events = h->chain_events;
     return 0;
 }
 

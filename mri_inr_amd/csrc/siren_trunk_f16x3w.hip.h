@@ -36,6 +36,10 @@
 
 namespace msiren {
 
+// depths the kernel is built and tested for: its unit images + (L + 1)-row modulation tables must fit the 160 KB of LDS
+// (L = 6 would need 166 992 B), and a pass needs a hidden layer on either side of the one in flight
+constexpr int WS_MIN_L = 3, WS_MAX_L = 5;
+
 // passes [0, n4) take 4 units each, [n4, n4 + n3) take 3, [n4 + n3, npasses) take 2 (the very last one may reach past
 // the end of the batch: its surplus unit is computed on clamped inputs and not stored)
 struct WsSchedule {
@@ -543,6 +547,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     } while (0)
 // Ablation builds (timing only, results wrong; never shipped): -DMSIREN_WS_ABL=bitmask (8: no MFMAs, see MSIREN_WS_MFMA)
 //   1 = no epilogue in the gaps, 2 = no B-fragment LDS reads, 4 = no barrier
+// Every VGPR-destination load this kernel issues through asm (layer-0 table, modulation rows, the queue atomic) is followed
+// by a counted s_waitcnt that carries the destination as an operand BEFORE anything else may touch those registers --
+// tests/test_asm_hazards.py checks that in the ISA.  Round 3's -DMSIREN_WS_ABL=15 build broke exactly this and faulted
+// (gpurun_out/r3/abl/abl15.err): bit 1 removed the gaps, and with them the MSIREN_WS_RAW0_WAITs and the final body's
+// output store that the boundary waits count on, but NOT the table loads in MSIREN_WS_PRE_B.  Their destinations were dead
+// on arrival, so the allocator handed the registers on (ISA of that build: `global_load_dwordx4 v[20:23]` ... no wait ...
+// `v_add_u32 v20, 0x10400, v0`; `ds_read_b128 v[20:23], v20`; in the other body variant v32/v33 -- destinations here --
+// are the OFFSET registers of the next table loads).  With MFMAs (ABL = 7) a slot lasts >= 3000 cycles and the data landed
+// before the registers were reused; without them (bit 8) a slot is shorter than a memory round trip, the late data
+// overwrote live offsets, and the next `global_load_dwordx4 ..., v32, s[..]` went wherever that pointed.  The shipped
+// build never had the hazard (0 of 89 such loads; the ablations: 45).  Since round 4 bit 1 also drops the loads whose
+// waits it drops, and the boundary waits that counted on the removed store drain instead.
 #ifndef MSIREN_WS_ABL
 #define MSIREN_WS_ABL 0
 #endif
@@ -568,8 +584,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
 #define MSIREN_WS_PRE_B(S)                                                                                           \
     do {                                                                                                             \
         if ((S) == 0) { MSIREN_WS_LD_MWT(0); MSIREN_WS_LD_MWT(1); MSIREN_WS_LD_MWT(2); MSIREN_WS_LD_MWT(3);          \
-                        l0_load_half(l0c0_, 0, raw0); }                                                              \
-        if ((S) == 2) { MSIREN_WS_LD_EM0(0); MSIREN_WS_LD_EM0(1); l0_load_half(l0c0_, 1, raw0); }                    \
+                        if (!(MSIREN_WS_ABL & 1)) l0_load_half(l0c0_, 0, raw0); } /* (no load without its wait) */   \
+        if ((S) == 2) { MSIREN_WS_LD_EM0(0); MSIREN_WS_LD_EM0(1); if (!(MSIREN_WS_ABL & 1)) l0_load_half(l0c0_, 1, raw0); } \
         if ((S) == 3) { MSIREN_WS_LD_EM0(2); MSIREN_WS_LD_EM0(3); }                                                  \
     } while (0)
 
@@ -693,7 +709,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         if (stage_mods) { /* (fetched a slot ago; behind it at most this slot's 64 weight loads, 8 table loads and, youngest, */ \
             /* a final body's output store -- which must NOT be waited for: a store takes ~1000 cycles to be acknowledged) */ \
             if ((FL) == 2) asm volatile("s_waitcnt vmcnt(63)" : "+v"(mnext[0]), "+v"(mnext[1]));                     \
-            else if (pv_final) asm volatile("s_waitcnt vmcnt(1)" : "+v"(mnext[0]), "+v"(mnext[1]));                  \
+            else if (pv_final && !(MSIREN_WS_ABL & 1)) asm volatile("s_waitcnt vmcnt(1)" : "+v"(mnext[0]), "+v"(mnext[1])); \
             else asm volatile("s_waitcnt vmcnt(0)" : "+v"(mnext[0]), "+v"(mnext[1]));                                \
             int r0n = row0 + L;                                                                                      \
             r0n = r0n >= NR ? r0n - NR : r0n;                                                                        \
@@ -704,7 +720,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         /* wait on the way), read by everybody another slot later (a barrier in between); needed from the final layer on */ \
         if (k_in_pass == 0) { /* the atomic was issued a whole slot ago; the body since was a final one (a pass's first */ \
             /* slot follows a final-layer slot): its output store is the one younger operation */                   \
-            asm volatile("s_waitcnt vmcnt(1)" : "+v"(fetched_id));                                                   \
+            if (MSIREN_WS_ABL & 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(fetched_id)); /* (no younger store / table loads there) */ \
+            else asm volatile("s_waitcnt vmcnt(1)" : "+v"(fetched_id));                                              \
             if (tid == 0) qslot[0] = (int)((unsigned)fetched_id - p.pass_base) + (int)gridDim.x;                     \
         }                                                                                                            \
         if (k_in_pass == 1) {                                                                                        \

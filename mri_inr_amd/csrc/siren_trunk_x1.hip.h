@@ -18,7 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "siren_trunk_f16x3.hip.h"
+#include "siren_trunk_f16_common.hip.h"
 
 namespace msiren {
 

@@ -128,6 +128,9 @@ class ModulatedSiren:
         elif encoder_path is not None:
             sd.update(self._load_encoder_checkpoint(encoder_path))
         self._sd = collections.OrderedDict(sd)
+        # the configuration's key set and shapes, fixed at construction: what _pull_tensors iterates over, so that keys a
+        # trunk-only blob dropped come back when a later blob carries them
+        self._shapes = collections.OrderedDict((k, tuple(v.shape)) for k, v in self._sd.items())
         self.grid = self._sd["grid"]
         if self._device is not None and _lib_device_available():
             self._ensure_handle()
@@ -188,18 +191,22 @@ class ModulatedSiren:
             _lib.check(self._lib.msiren_set_tensor(self._h, k.encode(), a.ctypes.data, a.size))
         self._committed = False
 
-    def _pull_tensors(self, drop_absent: bool = False):
-        """Refresh the host mirror from the tensors the handle holds (after msiren_broadcast_weights / _import)."""
+    def _pull_tensors(self):
+        """Refresh the host mirror from the tensors the handle holds (after msiren_broadcast_weights / _import): every
+        key of the configuration the handle holds is (re)stored, keys it does not hold (a trunk-only source: no encoder)
+        are dropped from ``state_dict()`` -- the same policy on the import and on the broadcast path."""
         self._ensure_handle()
-        for k, v in list(self._sd.items()):
-            a = np.empty(v.shape, dtype=np.float32)
+        old, new = self._sd, collections.OrderedDict()
+        for k, shape in self._shapes.items():
+            a = np.empty(shape, dtype=np.float32)
             rc = self._lib.msiren_get_tensor(self._h, k.encode(), a.ctypes.data, a.size)
-            if rc == _lib.E_STATE:  # the source rank did not hold it (e.g. no encoder)
-                if drop_absent and k != "grid":  # (the library rebuilds a missing grid buffer; the mirror keeps its own)
-                    del self._sd[k]
+            if rc == _lib.E_STATE:  # the source did not hold it
+                if k == "grid":     # (the library rebuilds a missing grid buffer; the mirror keeps its own)
+                    new[k] = old[k]
                 continue
             _lib.check(rc)
-            self._sd[k] = a
+            new[k] = a
+        self._sd = new
         self.grid = self._sd["grid"]
 
     def export_weights(self) -> np.ndarray:
@@ -222,7 +229,7 @@ class ModulatedSiren:
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         _lib.check(self._lib.msiren_weights_import(self._h, blob.ctypes.data, blob.size))
         self._committed = True
-        self._pull_tensors(drop_absent=True)
+        self._pull_tensors()
         return self
 
     def _ensure_committed(self):
@@ -236,6 +243,24 @@ class ModulatedSiren:
     def expected_keys(self):
         return list(self._sd.keys())
 
+    def last_trunk_kernel(self) -> str:
+        """Name of the trunk instance the handle's most recent trunk launch used (msiren_last_trunk_kernel)."""
+        self._ensure_handle()
+        buf = C.create_string_buffer(128)
+        _lib.check(self._lib.msiren_last_trunk_kernel(self._h, buf))
+        return buf.value.decode()
+
+    def profile_kernels(self) -> list:
+        """Per trunk instance since msiren_profile_enable(h, 1): name, launches, summed ms, coordinates evaluated."""
+        self._ensure_handle()
+        out, i = [], 0
+        while True:
+            buf, n, ms, co = C.create_string_buffer(128), C.c_int64(), C.c_double(), C.c_int64()
+            if self._lib.msiren_profile_read_kernel(self._h, i, buf, C.byref(n), C.byref(ms), C.byref(co)) != 0:
+                return out
+            out.append(dict(kernel=buf.value.decode(), launches=n.value, ms_total=ms.value, coords=co.value))
+            i += 1
+
     def state_dict(self):
         return collections.OrderedDict((k, np.array(v, copy=True)) for k, v in self._sd.items())
 
@@ -246,22 +271,22 @@ class ModulatedSiren:
             if _is_torch(v):
                 v = v.detach().cpu().numpy()
             new[k] = np.ascontiguousarray(v, dtype=np.float32)
-        missing = [k for k in self._sd if k not in new]
-        unexpected = [k for k in new if k not in self._sd]
+        # the key set is the configuration's (fixed at construction), not whatever the mirror holds after a trunk-only import
+        missing = [k for k in self._shapes if k not in new]
+        unexpected = [k for k in new if k not in self._shapes]
         errs = []
         if strict and unexpected:
             errs.append("Unexpected key(s) in state_dict: " + ", ".join(f'"{k}"' for k in unexpected) + ". ")
         if strict and missing:
             errs.append("Missing key(s) in state_dict: " + ", ".join(f'"{k}"' for k in missing) + ". ")
         for k, v in new.items():
-            if k in self._sd and tuple(v.shape) != tuple(self._sd[k].shape):
+            if k in self._shapes and tuple(v.shape) != self._shapes[k]:
                 errs.append(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from checkpoint, "
-                            f"the shape in current model is {tuple(self._sd[k].shape)}.")
+                            f"the shape in current model is {self._shapes[k]}.")
         if errs:
             raise RuntimeError("Error(s) in loading state_dict for ModulatedSiren:\n\t" + "\n\t".join(errs))
-        for k, v in new.items():
-            if k in self._sd:
-                self._sd[k] = v
+        self._sd = collections.OrderedDict((k, new[k] if k in new else self._sd[k]) for k in self._shapes
+                                           if k in new or k in self._sd)  # (construction order, whatever came back)
         self.grid = self._sd["grid"]
         self._committed = False
         if self._h is not None:
@@ -446,6 +471,10 @@ class ModulatedSiren:
     def sync(self):
         self._ensure_handle()
         _lib.check(self._lib.msiren_sync(self._h))
+
+    def device_string(self) -> str:
+        """"cuda:<index>" of the device the model lives on (what ``.to()`` takes)."""
+        return f"cuda:{self._device}"
 
     def device_info(self) -> dict:
         self._ensure_handle()

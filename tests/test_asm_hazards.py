@@ -113,25 +113,89 @@ def _scan(body, asm_mfma):
     return bad, checked, closest
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_wait_states_around_asm_issued_instructions(tmp_path):
-    src = tmp_path / "hz.hip"
-    src.write_text(TU)
-    asm = tmp_path / "hz.s"
+def _compile(tmp, tu, name, extra=()):
+    src = tmp / f"{name}.hip"
+    src.write_text(tu)
+    asm = tmp / f"{name}.s"
     cmd = [HIPCC, "-O3", "-std=c++17", "-S", "--cuda-device-only", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "mri_inr_amd", "csrc"),
-           "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-fno-slp-vectorize", str(src), "-o", str(asm)]
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-fno-slp-vectorize", *extra, str(src), "-o", str(asm)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
     assert res.returncode == 0, res.stderr[-3000:]
-    text = asm.read_text()
+    return asm.read_text()
+
+
+@pytest.fixture(scope="module")
+def trunk_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    text = _compile(tmp_path_factory.mktemp("hz"), TU, "hz")
     kernels = re.split(r"\n(?=_ZN6msiren\d+siren_trunk_f16x3[nhw]_kernel)", text)[1:]
     assert len(kernels) == 7, len(kernels)
+    return [(k.split(":")[0], k.split(".amdhsa_kernel")[0]) for k in kernels]
+
+
+def test_wait_states_around_asm_issued_instructions(trunk_isa):
     total = 0
-    for k in kernels:
-        name = k.split(":")[0]
-        body = k.split(".amdhsa_kernel")[0]
+    for name, body in trunk_isa:
         bad, checked, closest = _scan(body, "f16x3w" in name)
         print(f"{name}: {checked} accesses to MFMA results checked, closest {closest} wait states behind the MFMA")
         assert not bad, name + "\n" + "\n".join(bad[:20])
         assert checked > 100, (name, checked)   # the scan did see the epilogue reading accumulators
         total += checked
     assert total > 3000
+
+
+def _scan_loads_in_flight(body):
+    """Every vector-memory operation that returns data into VGPRs must be covered by an s_waitcnt vmcnt BEFORE anything
+    reads or overwrites its destination.  The compiler guarantees that for loads it issues itself; for loads issued
+    through asm (the weight-stationary trunk's table, modulation and queue loads) it only holds while every such asm
+    statement is followed by a wait that carries the destination as an operand -- otherwise the registers are dead on
+    arrival and get handed on while the data is still in flight, which is how round 3's -DMSIREN_WS_ABL=15 build faulted
+    (siren_trunk_f16x3w.hip.h, "Ablation builds").  Program order; vmcnt(N) retires all but the N youngest operations
+    (in-order return on gfx9); an unconditional branch ends the path.  Returns (violations, loads seen)."""
+    out, bad, seen = [], [], 0   # outstanding operations, oldest first: [line, text, set of destination VGPRs]
+    for i, raw in enumerate(body.splitlines()):
+        line = raw.split(";")[0].strip()
+        if not line or line.endswith(":") or line.startswith("."):
+            continue
+        parts = line.split(None, 1)
+        op = parts[0]
+        ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        ops = [o.split()[0] if o.split() else o for o in ops]
+        if op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", line)
+            if m:
+                n = int(m.group(1))
+                out = out[len(out) - n:] if 0 < n < len(out) else ([] if n == 0 else out)
+            continue
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            out = []
+            continue
+        touched = set(r for o in ops for r in _regs(o))
+        for rec in out:
+            hit = touched & rec[2]
+            if hit:
+                bad.append(f"v{sorted(hit)[0]} touched by `{raw.strip()}` (line {i + 1}) while `{rec[1].strip()}` (line {rec[0] + 1}) may be in flight")
+                rec[2] -= hit
+        if op.startswith(("global_", "buffer_", "flat_")):
+            returns = (op.startswith(("global_load", "buffer_load", "flat_load")) and "_lds_" not in op) or \
+                      (op.startswith("global_atomic") and "sc0" in raw)   # (global_load_lds_*: the VGPR operand is the address)
+            dst = set(_regs(ops[0])) if (returns and ops and ops[0].startswith("v")) else set()
+            seen += bool(dst)
+            out.append([i, raw, dst])
+    return bad, seen
+
+
+def test_no_load_destination_is_touched_while_the_load_is_in_flight(trunk_isa, tmp_path):
+    for name, body in trunk_isa:
+        bad, seen = _scan_loads_in_flight(body)
+        print(f"{name}: {seen} VGPR-destination vector-memory operations, {len(bad)} touched before a covering wait")
+        assert not bad, name + "\n" + "\n".join(bad[:10])
+        assert seen >= 8, (name, seen)
+    # the ablation builds of the weight-stationary trunk (timing only, never shipped) must stay safe to RUN as well
+    ws = ('#include <hip/hip_runtime.h>\n#include "siren_trunk_f16x3w.hip.h"\n'
+          "template __global__ void msiren::siren_trunk_f16x3w_kernel<0, 4, 0>(msiren::TrunkWsParams);\n")
+    for abl in (7, 15):
+        text = _compile(tmp_path, ws, f"abl{abl}", extra=(f"-DMSIREN_WS_ABL={abl}",))
+        bad, seen = _scan_loads_in_flight(text.split(".amdhsa_kernel")[0])
+        assert not bad, f"MSIREN_WS_ABL={abl}\n" + "\n".join(bad[:10])

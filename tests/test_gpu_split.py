@@ -1,0 +1,172 @@
+"""Large asynchronous calls overlap with themselves (mri_inr_amd/csrc/msiren.hip: forward_tiles_split), and the paths the
+benchmark's timed region runs are checked against the reference's fixtures DIRECTLY (not through another path's output).
+
+On a one-stream handle a call of >= 3200 tiles is cut in two: the encoder + Modulator of most of the batch run on the handle's other stream
+beside the register-resident trunk of the first part, the weight-stationary trunk of the rest follows.  Patches are
+independent (modulated_siren.py:435-457) and the two trunks give the same bits, so nothing may change.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from mri_inr_amd import _lib, synthetic as syn
+from oracle import siren_oracle as orc
+from test_gpu_parity import check, make_model
+
+pytestmark = pytest.mark.gpu
+
+
+def make_with_env(sd, env, **kw):
+    """The knobs are read once, at msiren_create."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return make_model(sd, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def run_dev(m, d_in, n, d_out):
+    _lib.check(m._lib.msiren_forward_tiles_dev(m._h, d_in.ptr, n, d_out.ptr))
+
+
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_split_call_same_bits_as_uncut_call(act):
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    B = 3300
+    tiles = np.random.default_rng(11).random((B, 32, 32), dtype=np.float32)
+    whole = make_with_env(sd, {"MSIREN_SPLIT_MIN": 0}, act=act, precision="f16x3")
+    d_in, d_out = whole.device_array(tiles.shape).copy_from(tiles), whole.device_array((B, 24, 24))
+    run_dev(whole, d_in, B, d_out)
+    whole.sync()
+    ref = d_out.numpy()
+    assert whole.last_trunk_kernel().startswith("siren_trunk_f16x3w_kernel")
+    check(ref[:32], orc.modulated_siren_forward(sd, tiles[:32], num_layers=5, activation=act, dtype=np.float64))
+    check(ref[-32:], orc.modulated_siren_forward(sd, tiles[-32:], num_layers=5, activation=act, dtype=np.float64))
+    a = 1 if act == "morlet" else 0
+    for env in ({}, {"MSIREN_SPLIT_PCT": 30}, {"MSIREN_SPLIT_PCT": 1}, {"MSIREN_SPLIT_MIN": 3300}):
+        m = make_with_env(sd, env, act=act, precision="f16x3")
+        d_i, d_o = m.device_array(tiles.shape).copy_from(tiles), [m.device_array((B, 24, 24)) for _ in range(2)]
+        for streams in (1, 2):
+            _lib.check(m._lib.msiren_set_streams(m._h, streams))
+            _lib.check(m._lib.msiren_profile_enable(m._h, 1))
+            for k in range(4):   # back to back: the second part's modulations cross streams, call after call
+                run_dev(m, d_i, B, d_o[k & 1])
+            m.sync()
+            ks = {k["kernel"]: k for k in m.profile_kernels()}
+            _lib.check(m._lib.msiren_profile_enable(m._h, 0))
+            assert sum(k["coords"] for k in ks.values()) == 4 * B * 576 and all(k["launches"] == 4 for k in ks.values())
+            if streams == 1:   # the call overlaps with itself
+                assert set(ks) == {f"siren_trunk_f16x3n_kernel<{a},3,5>", f"siren_trunk_f16x3w_kernel<{a},4>"}, ks
+                assert ks[f"siren_trunk_f16x3w_kernel<{a},4>"]["coords"] > ks[f"siren_trunk_f16x3n_kernel<{a},3,5>"]["coords"]
+            else:              # two streams: consecutive calls overlap with each other, nothing is cut
+                assert set(ks) == {f"siren_trunk_f16x3n_kernel<{a},3,5>"}, ks
+            for o in d_o:
+                assert np.array_equal(o.numpy(), ref), (env, streams)
+        # the synchronous host call goes the same way
+        assert np.array_equal(m(tiles), ref)
+        # below the threshold nothing is cut
+        _lib.check(m._lib.msiren_set_streams(m._h, 1))
+        run_dev(m, d_i, 3100, d_o[0])
+        m.sync()
+        assert m.last_trunk_kernel() == f"siren_trunk_f16x3w_kernel<{a},4>"
+        assert np.array_equal(d_o[0].numpy()[:3100], ref[:3100])
+
+
+def test_split_is_not_taken_where_it_does_not_apply():
+    """Other depths, the exact-fp32 trunk and the masked slice pipeline (tile count known to the device only) run uncut."""
+    tiles = np.random.default_rng(12).random((3300, 32, 32), dtype=np.float32)
+    for L, prec in ((4, "f16x3"), (5, "fp32")):
+        sd = syn.make_state_dict(seed=3, num_layers=L, trained_like=True)
+        m = make_model(sd, L=L, precision=prec)
+        _lib.check(m._lib.msiren_profile_enable(m._h, 1))
+        out = m(tiles)
+        assert len(m.profile_kernels()) == 1
+        check(out[:16], orc.modulated_siren_forward(sd, tiles[:16], num_layers=L, dtype=np.float64))
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = make_model(sd)
+    imgs = np.stack([syn.make_slice(k, brain_mask=True) for k in range(9)])
+    _lib.check(m._lib.msiren_profile_enable(m._h, 1))
+    rec = m.reconstruct(imgs)
+    assert len(m.profile_kernels()) == 1
+    assert np.array_equal(rec[8], m.reconstruct(imgs[8]))
+
+
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_two_stream_headline_path_vs_reference_fixture(act):
+    """What bench.py's timed region runs: msiren_set_streams(h, 2), alternating msiren_forward_tiles_dev calls (the
+    register-resident trunk beside the next call's encoder / Modulator) -- every output against the REFERENCE's."""
+    g = load_golden(f"forward_trained_{act}.npz")
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = make_model(sd, act=act, precision="f16x3")
+    tiles = np.random.default_rng(42).random((8, 32, 32), dtype=np.float32)   # the fixture's input (oracle/gen_fixtures.py)
+    big = np.concatenate([tiles] * 50)                                          # 400 tiles: the full-size kernel instances
+    d_in, d_big = m.device_array(tiles.shape).copy_from(tiles), m.device_array(big.shape).copy_from(big)
+    d_out = [m.device_array((8, 24, 24)) for _ in range(6)]
+    d_bout = [m.device_array((400, 24, 24)) for _ in range(6)]
+    _lib.check(m._lib.msiren_set_streams(m._h, 2))
+    for k in range(6):
+        run_dev(m, d_big, 400, d_bout[k])
+        if k == 0:
+            assert m.last_trunk_kernel() == f"siren_trunk_f16x3n_kernel<{1 if act == 'morlet' else 0},3,5>"
+        run_dev(m, d_in, 8, d_out[k])
+    m.sync()
+    for o in d_out:
+        check(o.numpy(), g["out"])
+    for o in d_bout:
+        got = o.numpy().reshape(50, 8, 24, 24)
+        for r in (0, 17, 49):
+            check(got[r], g["out"])
+
+
+def test_full_slice_reconstruct_vs_fp64_oracle():
+    """One full 320x320 masked slice through the device pipeline (tiles -> black filter -> forward -> weighted fold)
+    against the oracle's float64 reconstruction (tiling.py:10-140,244-303 + modulated_siren.py:435-457)."""
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = make_model(sd)
+    img = syn.make_slice(2, brain_mask=True)
+    ref = orc.reconstruct_slice(sd, img, num_layers=5, dtype=np.float64)
+    rec = m.reconstruct(img)
+    check(rec, ref)
+    _lib.check(m._lib.msiren_set_streams(m._h, 2))
+    d_img, d_rec = m.device_array((1, 320, 320)).copy_from(img[None]), [m.device_array((1, 320, 320)) for _ in range(2)]
+    for k in range(4):
+        _lib.check(m._lib.msiren_reconstruct_slices_dev(m._h, d_img.ptr, 1, 320, 320, d_rec[k & 1].ptr))
+    m.sync()
+    for o in d_rec:
+        assert np.array_equal(o.numpy()[0], rec)
+
+
+@pytest.mark.parametrize("H,Z,L,B", [(256, 256, 5, 1100), (256, 256, 5, 1037), (64, 48, 3, 1030), (48, 16, 2, 1025), (512, 128, 10, 1056)])
+def test_tiled_linear_layers_same_bits_as_the_16x16_kernel(H, Z, L, B):
+    """Throughput sizes run conv3, Linear(64, Z) and the Modulator layers on 32 x 32 output tiles
+    (linear_mfma_tile_kernel<2, 2>), latency sizes on 16 x 16: same MFMA chains, same K split, same reduction order --
+    `self.modulator(self.encoder(tiles))` (modulated_siren.py:446) must not depend on the batch a tile came in."""
+    kw = dict(dim_hidden=H, num_layers=L, latent_dim=Z)
+    sd = syn.make_state_dict(seed=21, trained_like=True, **kw) if H != 512 else \
+        syn.make_state_dict(seed=21, modulator_bias_center=0.25, encoder_gain=10.0, **kw)
+    mk = dict(H=H, L=L, Z=Z, precision="fp32")
+    small = make_with_env(sd, {"MSIREN_LINEAR_TILE_MIN": 0}, **mk)
+    tiled = make_with_env(sd, {"MSIREN_LINEAR_TILE_MIN": 1}, **mk)
+    auto = make_model(sd, **mk)   # default threshold: 1024 rows
+    tiles = np.random.default_rng(B).random((B, 32, 32), dtype=np.float32)
+    z = small.encoder(tiles)
+    assert np.array_equal(tiled.encoder(tiles), z) and np.array_equal(auto.encoder(tiles), z)
+    assert np.array_equal(auto.encoder(tiles[:70]), z[:70])          # (16 x 16 kernel in the same handle)
+    check(z[:40], orc.encoder_forward(sd, tiles[:40], dtype=np.float64), tol=1e-5)
+    mods = small.modulator(z)
+    for a, b, c in zip(mods, tiled.modulator(z), auto.modulator(z)):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    ref = orc.modulator_forward(sd, z[:40].astype(np.float64), num_layers=L, dtype=np.float64)
+    for a, r in zip(mods, ref):
+        check(a[:40], r, tol=1e-5)
+    # the masked slice pipeline hands the row count over on the device
+    if H == 256:
+        imgs = np.stack([syn.make_slice(k, brain_mask=True) for k in range(5)])
+        assert np.array_equal(small.reconstruct(imgs), tiled.reconstruct(imgs))

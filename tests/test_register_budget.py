@@ -17,14 +17,12 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 TU = r"""
 #include <hip/hip_runtime.h>
-#include "siren_trunk_f16x3.hip.h"
 #include "siren_trunk_f16x3n.hip.h"
 #include "encoder_modulator.hip.h"
 #include "tiling.hip.h"
-template __global__ void msiren::siren_trunk_f16x3_kernel<0, 3, 0>(msiren::TrunkF16Params);
-template __global__ void msiren::siren_trunk_f16x3_kernel<1, 3, 0>(msiren::TrunkF16Params);
 template __global__ void msiren::siren_trunk_f16x3n_kernel<0, 3, 5>(msiren::TrunkF16Params);
 template __global__ void msiren::siren_trunk_f16x3n_kernel<1, 3, 5>(msiren::TrunkF16Params);
+template __global__ void msiren::linear_mfma_tile_kernel<2, 2>(msiren::ModulatorMfmaParams);
 """
 
 
@@ -53,7 +51,7 @@ def test_trunk_and_its_neighbours_fit_on_one_cu(tmp_path):
     usage = _usage(tmp_path)
     trunks = {k: v for k, v in usage.items() if "siren_trunk_f16x3" in k}
     beside = {k: v for k, v in usage.items() if k not in trunks}
-    assert len(trunks) == 4 and len(beside) >= 7, list(usage)  # 32x32x16 (A/B reference) and 16x16x32 (default), sine / Morlet
+    assert len(trunks) == 2 and len(beside) >= 8 and any("linear_mfma_tile" in k for k in beside), list(usage)  # the register-resident 16x16x32 trunk, sine / Morlet
 
     def alloc(u):  # registers one wave occupies in the unified 512-entry file of a SIMD lane (gfx90a+)
         acc_offset = (u["VGPRs"] + 3) // 4 * 4

@@ -1,124 +1,10 @@
-// Fused modulated-SIREN trunk for gfx950, split-fp16 path ("f16x3"): fp32-equivalent accuracy at
-// 3/16 of the fp32-MFMA cost.  This is round 1's kernel on 32x32x16 MFMA tiles; since round 2 the library
-// ships siren_trunk_f16x3n.hip.h (16x16x32 tiles, same arithmetic and data flow, built on the types and
-// helpers below) and compiles this kernel only as the A/B reference (make AB32=1, MSIREN_F16_TILE=32).
-//
-// Arithmetic.  Every hidden-layer operand is split into two fp16 numbers, v = hi + lo exactly-ish
-// (hi = f16(v), lo = f16(v - hi); 22 significant bits), and the product is evaluated as
-//     W*x  ~=  W_lo*x_hi + W_hi*x_lo + W_hi*x_hi        (the lo*lo term, 2^-22 relative, is dropped)
-// with three v_mfma_f32_32x32x16_f16 accumulating in fp32.  Weights are split once on the host after
-// scaling by a power of two (so that W_lo stays clear of the fp16 subnormal range; the exact inverse
-// scale is folded into the epilogue FMA); activations are split in the epilogue.  gfx950's MFMA keeps
-// fp16 subnormal inputs (tools/f16_probe.hip), so x_lo needs no scaling.  Measured against the fp64
-// oracle this path is indistinguishable from true fp32 (tests/test_gpu_parity.py).
-//
-// Data flow (reference: src/networks/modulated_siren.py:215-233).
-//   workgroup = 4 waves, ONE per SIMD (the kernel owns the whole 512-register file); persistent grid,
-//   one workgroup per CU.  A wave evaluates one UNIT = 32 coordinates of one patch through all layers
-//   with its activations in REGISTERS: the fp32 accumulator tile of layer l (features on registers,
-//   coordinate on the lane) is, after the epilogue, bit for bit the B operand of layer l+1 -- no LDS
-//   round trip, no barrier for activations (the k order inside a step is permuted accordingly and the
-//   host packs the weights in that order).
-//   The weights are the operand every wave shares: the stream of 32 KB chunks
-//   [layer][feature tile][k-step][hi|lo][lane][8 x f16] is DMA'd (global_load_lds_dwordx4) into a ring
-//   in LDS, two to three chunks ahead, and read back with one conflict-free ds_read_b128 per MFMA.
-//   One s_barrier per chunk (48 MFMAs) orders ring reuse.  The epilogue of tile t (VALU: FMA, v_sin,
-//   modulation, fp16 split) is issued in the same scheduling region as the MFMAs of tile t+1.
+// RECORD ONLY -- not part of the product build since round 4 (DESIGN.md §4.2a has its measurements).
+// Round 1's split-fp16 trunk on 32x32x16 MFMA tiles; it built against mri_inr_amd/csrc at commit 8569a88
+// (make AB32=1, MSIREN_F16_TILE=32).  The shared definitions it used now live in siren_trunk_f16_common.hip.h.
 #pragma once
-#include <hip/hip_runtime.h>
-
-#include "siren_trunk_f32.hip.h"
+#include "../../mri_inr_amd/csrc/siren_trunk_f16_common.hip.h"
 
 namespace msiren {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-struct TrunkF16Params {
-    const float* grid;        // (P,2)
-    const float* l0;          // (256,4) {w_row, w_col, b, 0} * w0_initial/2pi
-    const float* s0t;         // (64, P, 4): layer-0 activations act0(W0 x_p + b0) before modulation, feature-group major
-    const _Float16* wp;       // [(L-1)*8 chunks][16 k-steps][2: hi,lo][64 lanes][8]
-    const float* bias;        // (L-1, 256) in revolutions
-    const float* wout;        // (256) * w0/2pi
-    const float* mods;        // (L, B, 256)
-    float* out;               // (B, P)
-    float winv[16];           // per hidden layer: exact inverse of the power-of-two weight scale
-    float bout, cg0, cg;
-    int B, P, L, units_per_patch, total_units;
-    int unit_base;            // first unit of this launch (16x16x32 kernels; a launch covers [unit_base, unit_base + total_units))
-    const int* plan;          // optional (compact_flags_kernel): the unit count is plan[1] (<= total_units)
-    int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
-    unsigned pass_base;        // value of *pass_counter when this launch starts (arithmetic is modulo 2^32)
-    unsigned long long* stamps; // diagnostic instantiation only: [grid][8 passes][8] s_memtime + realtime
-    int* status;              // domain guard: set to 1 when a scaled modulation does not fit fp16 (host-mapped word; may be null)
-};
-
-constexpr int F16_CHUNK_BYTES = 32768;
-
-template <int R>
-struct F16Lds {  // byte offsets into dynamic LDS
-    static constexpr int ring = 0;
-    static constexpr int l0 = R * F16_CHUNK_BYTES;  // 256 x float4
-    static constexpr int wout = l0 + 4096;          // 256 floats
-    static constexpr int zero = wout + 1024;        // 256 floats of 0 (stand-in for wout on non-final layers)
-    static constexpr int bias = zero + 1024;        // (L-1) x 256 floats
-    static __host__ __device__ constexpr int mods(int L) { return bias + (L - 1) * 1024; }  // 4 waves x L x 256 floats
-    static __host__ __device__ constexpr int queue(int L) { return mods(L) + 4 * L * 1024; }  // 2 ints: next pass id
-    static __host__ __device__ constexpr int winv(int L) { return queue(L) + 16; }  // per-layer inverse weight scales
-    static __host__ __device__ constexpr int total(int L) { return winv(L) + 64; }
-};
-
-// Domain of the split-fp16 arithmetic on the activation side: x' = a * (m * 2^-a_next) is rounded to fp16 (hi) with |a| <= 1,
-// so a scaled modulation beyond fp16's largest finite value (or a NaN / inf) would give inf / NaN silently.  Checked where the
-// modulation rows are staged (a handful of compares per unit); the flag is a word in host memory the library reads at its
-// next synchronisation (MSIREN_E_RANGE, or the exact-fp32 re-run of a host-pointer call).
-__device__ __forceinline__ bool f16_out_of_range(const f32x4 m) {
-    return !(__builtin_fabsf(m[0]) <= 65504.f) || !(__builtin_fabsf(m[1]) <= 65504.f) || !(__builtin_fabsf(m[2]) <= 65504.f) ||
-           !(__builtin_fabsf(m[3]) <= 65504.f);
-}
-
-__device__ __forceinline__ h8 pack_h8(fp16x2 a, fp16x2 b, fp16x2 c, fp16x2 d) {
-    u32x4 u;
-    u[0] = __builtin_bit_cast(unsigned, a);
-    u[1] = __builtin_bit_cast(unsigned, b);
-    u[2] = __builtin_bit_cast(unsigned, c);
-    u[3] = __builtin_bit_cast(unsigned, d);
-    return __builtin_bit_cast(h8, u);
-}
-
-// Register-file placement.  The kernel keeps 256 registers of activations (this layer's and the next
-// layer's B operands) live for a whole layer; they only fit if they sit in the ACCUMULATOR half of the
-// unified 512-register file, which MFMA can read B from directly.  Left alone hipcc keeps builtin-MFMA
-// operands in arch VGPRs (and then spills ~300 of them), so the placement is pinned here: every B
-// fragment passes through an "a"-constrained asm once, when produced; the MFMAs themselves are the
-// builtin, compiled with -mllvm -amdgpu-mfma-vgpr-form=1 (A and the accumulator in arch VGPRs).
-__device__ __forceinline__ h8 to_acc_file(h8 v) {
-    h8 r;
-    asm("; activation fragment -> AGPR" : "=a"(r) : "0"(v));
-    return r;
-}
-// D = A*B (first k-step of a tile: C = 0) and D += A*B.  A (weights) and the accumulator in arch VGPRs,
-// B (activations) in AGPRs: 2 x 128 activation registers fill the accumulator half.  Builtins: hipcc
-// inserts whatever hazard padding the operands need.
-__device__ __forceinline__ void mfma_f16_first(f32x16& d, const h8& a, const h8& b) {
-    f32x16 z;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, z, 0, 0, 0);
-}
-__device__ __forceinline__ void mfma_f16_acc(f32x16& d, const h8& a, const h8& b) {
-    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, d, 0, 0, 0);
-}
-
-// v (fp32) -> hi, lo (fp16, round toward zero; lo absorbs hi's truncation error exactly)
-__device__ __forceinline__ void split4(const f32x4 v, fp16x2& h01, fp16x2& h23, fp16x2& l01, fp16x2& l23) {
-    h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-    h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-    l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
-    l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
-}
 
 template <int ACT, int R, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3_kernel(TrunkF16Params p) {
