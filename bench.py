@@ -77,6 +77,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--check", action="store_true", help="also verify one batch against the oracle")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="self-launched ranks: wall limit of the whole job")
+    ap.add_argument("--scaling-selftest", action="store_true",
+                    help="run the N = 1 measurement twice -- plainly, and through the launcher path (one rank with "
+                         "RANK / WORLD_SIZE=1 / MASTER_* set, what a scaling sweep's N = 1 point goes through) -- and fail "
+                         "unless the two values agree within 3 %%")
     return ap.parse_args(argv)
 
 
@@ -203,6 +207,13 @@ class TorchGroup:
     def min(self, v):
         return -self.max(-v)
 
+    def max_array(self, values):
+        if self.world == 1:
+            return [float(x) for x in values]
+        t = self.torch.tensor([float(x) for x in values], dtype=self.torch.float64, device=self.device or "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
     def info(self):
         return (self.dist.get_world_size(), self.dist.get_rank()) if self.world > 1 else (1, 0)
 
@@ -218,6 +229,8 @@ def main():
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be positive")
+    if args.scaling_selftest:
+        sys.exit(scaling_selftest(args))
     if args.gpus > 1 and not launch.under_launcher():
         # no launcher around us: become one.  Nothing in this process has touched HIP (or imported torch).
         rc, _ = launch.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
@@ -308,6 +321,29 @@ def main():
     if sum_max != sum_min:
         raise SystemExit(f"[rank {rank}] ranks disagree on the probe output (checksum {probe_sum:.0f}, max {sum_max:.0f}, "
                          f"min {sum_min:.0f}): the weight broadcast did not replicate rank 0's state_dict")
+
+    # Who sits where: every rank fills its own row of a (world x 9) table -- device index, PCI bus id (domain, bus, device,
+    # function), CUs, clock, HBM, what its communicator says its rank is -- and one MAX-reduce hands rank 0 all of it
+    # (config.ranks[]): the first run on a real 8-GPU node can be read without a second one.
+    info0 = model.device_info()
+    try:
+        dom, bus, devfn = info0["pci_bus_id"].split(":")
+        pci = [int(dom, 16), int(bus, 16), int(devfn.split(".")[0], 16), int(devfn.split(".")[1], 16)]
+    except Exception:  # noqa: BLE001
+        pci = [-1, -1, -1, -1]
+    NF = 9
+    table = [-1.0] * (world * NF)
+    table[rank * NF:(rank + 1) * NF] = [float(dev)] + [float(x) for x in pci] + \
+        [float(info0["compute_units"]), float(info0["clock_mhz"]), float(info0["hbm_bytes"] >> 20), float(comm_rank)]
+    table = group.max_array(table)
+    ranks_info = []
+    for r in range(world):
+        row = table[r * NF:(r + 1) * NF]
+        ranks_info.append({"rank": r, "device": int(row[0]),
+                           "pci_bus_id": "%04x:%02x:%02x.%x" % tuple(int(x) for x in row[1:5]) if row[1] >= 0 else None,
+                           "compute_units": int(row[5]), "clock_mhz": int(row[6]), "hbm_mib": int(row[7]), "comm_rank": int(row[8])})
+    if world > 1 and len({(x["pci_bus_id"]) for x in ranks_info}) < world and backend != "gloo" and not os.environ.get("MSIREN_BENCH_ALLOW_SHARED"):
+        raise SystemExit(f"[rank {rank}] two ranks report the same PCI device: {ranks_info}")
 
     # ---- synthetic input: slice k = default_rng(1000+k).random((320,320)), tiled 32/16 on the device ----
     if args.total_slices:
@@ -519,6 +555,7 @@ def main():
             "comm_ranks": comm_ranks,
             "rccl_lib": (os.environ.get("MSIREN_RCCL_LIB") or "system librccl") if backend == "rccl" and world > 1 else None,
             "ranks_hold_identical_weights": bool(sum_max == sum_min), "probe_checksum": probe_sum,
+            "ranks": ranks_info,
             "warmup_steps_run": warm_steps,
         },
         "roofline": roof,
@@ -607,6 +644,45 @@ def extras(model, lib, h, _lib, d_img, d_tiles, d_recons, streams, budget_s=0.5)
     return {"host_to_host_mpixel_s": h2h, "reconstruct_mpixel_s": rec,
             "note": "one 320x320 slice per call, after the timed region: host numpy -> host numpy through "
                     "msiren_forward_tiles (PCIe-inclusive), and the device-resident slice -> slice pipeline"}
+
+
+def scaling_selftest(args) -> int:
+    """The N = 1 point of a scaling sweep goes through the launcher (RANK / WORLD_SIZE = 1 set by torchrun or spawn_ranks); the
+    BENCH line does not.  Run both here, back to back on the same card, and compare: if they differ by more than 3 % the
+    scaling curve's base is not the number the single-GPU line reports.  Prints ONE JSON line; exit code 1 on disagreement."""
+    import io
+    import subprocess
+
+    from mri_inr_amd import launch
+
+    if launch.under_launcher():
+        raise SystemExit("--scaling-selftest starts its own processes: run it without a launcher")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--slices", str(args.slices), "--streams", str(args.streams), "--no-cpu-baseline", "--no-extras"]
+    if args.total_slices:
+        cmd += ["--total-slices", str(args.total_slices)]
+    env = {k: v for k, v in os.environ.items() if k not in launch.ENV_KEYS}
+    vals = {}
+    for name in ("plain", "launched", "plain_again"):
+        if name == "launched":
+            out = io.StringIO()
+            rc, text = launch.spawn_ranks(cmd, 1, timeout=args.launch_timeout, env=env, stdout=out)
+        else:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=args.launch_timeout)
+            rc, text = r.returncode, r.stdout
+            sys.stderr.write(r.stderr[-2000:])
+        lines = [l for l in text.splitlines() if l.startswith("{")]
+        if rc != 0 or len(lines) != 1:
+            print(json.dumps({"selftest": "scaling", "ok": False, "error": f"{name} run failed (rc {rc})"}), flush=True)
+            return 1
+        vals[name] = json.loads(lines[0])["value"]
+    base = 0.5 * (vals["plain"] + vals["plain_again"])
+    rel = abs(vals["launched"] - base) / base
+    noise = abs(vals["plain"] - vals["plain_again"]) / base
+    ok = rel <= 0.03
+    print(json.dumps({"selftest": "scaling", "ok": ok, "unit": "Mpixel/s", **vals, "launched_vs_plain_rel_diff": rel,
+                      "plain_run_to_run_rel_diff": noise, "tolerance": 0.03}), flush=True)
+    return 0 if ok else 1
 
 
 def side_measure(model, n_slices, streams, steps, warmup, peak, seconds=0.25):

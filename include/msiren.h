@@ -44,8 +44,8 @@ enum {
     MSIREN_E_SHAPE = -3,    /* tensor size does not match the configuration (load_state_dict) */
     MSIREN_E_HIP = -4,      /* HIP runtime error (message carries hipGetErrorString)          */
     MSIREN_E_NOMEM = -5,
-    MSIREN_E_RANGE = -6     /* an operand left the domain of the handle's arithmetic (split-fp16 trunk: a modulation
-                               beyond what fp16 carries, or a NaN / inf); reported by the next synchronising call */
+    MSIREN_E_RANGE = -6     /* (rounds 2-3: an operand left the domain of the split-fp16 trunk.  Not returned since round 4:
+                               such launches are re-run on the exact-fp32 trunk on the stream itself, "Domain guard" below) */
 };
 
 enum { MSIREN_ACT_SINE = 0, MSIREN_ACT_MORLET = 1 };
@@ -59,9 +59,10 @@ enum {
                              fp32-equivalent accuracy (22-bit operands); H = 256, 2 <= L <= 11 (the
                              per-layer tables must fit the 160 KB LDS beside the weight ring; depths
                              3..5 run the weight-stationary kernel on single-stream handles).
-                             Other shapes silently use MSIREN_PREC_F32.  A modulation, activation or
-                             weight outside what fp16 operands can carry makes the forward call fail
-                             with MSIREN_E_RANGE instead of returning inf / NaN (see msiren_sync). */
+                             Other shapes silently use MSIREN_PREC_F32.  A launch that meets a modulation
+                             outside what fp16 operands can carry is followed, on the same stream, by the
+                             exact-fp32 trunk over the same batch (a conditional launch: "Domain guard"
+                             below) -- the output is the reference's fp32 result either way. */
     MSIREN_PREC_F16 = 3   /* as BF16 with fp16 operands (11-bit significand)                        */
 };
 
@@ -272,17 +273,18 @@ MSIREN_API int msiren_last_trunk_kernel(msiren_handle h, char* name128);
 /* name (<=255 chars + NUL), compute units, clock in MHz, total HBM bytes of the handle's device. */
 MSIREN_API int msiren_device_info(msiren_handle h, char* name256, int32_t* compute_units, int32_t* clock_mhz,
                        uint64_t* hbm_bytes);
+/* PCI bus id of the handle's device, "0000:c1:00.0" (<= 31 chars + NUL): which physical card a rank of a multi-GPU job sits on. */
+MSIREN_API int msiren_device_pci(msiren_handle h, char* busid32);
 MSIREN_API int msiren_device_count(int32_t* count);
 /* Domain guard of the split-fp16 trunk (MSIREN_PREC_F16X3).  Its fp16 operands carry activation x modulation x the next
  * layer's power-of-two weight scale; the weights are scaled into range at commit, a modulation cannot be known before the
- * call.  Every trunk launch checks the scaled modulations it stages: if one exceeds 65504 (or is not finite) a flag is raised
- * and
- *   - a host-pointer call (msiren_forward_mods / _latent / _tiles, msiren_reconstruct_slices) runs itself again on the
- *     exact-fp32 trunk and returns that result;
- *   - after *_dev calls the next msiren_sync (or any other synchronising call) returns MSIREN_E_RANGE: the outputs since
- *     the previous sync are not valid.
- * The reference's fp32 arithmetic (modulated_siren.py:215-233) has no such bound; this is what keeps "auto" precision from
- * returning inf / NaN where it would not.  msiren_range_events: launches that raised the flag since msiren_create. */
+ * call.  Every f16x3 trunk launch checks the scaled modulations it stages; if one exceeds 65504 (or is not finite) it
+ * writes its launch number to a word in device memory.  Behind every such launch -- host-pointer and *_dev entry points
+ * alike, one stream or two -- the library enqueues the exact-fp32 trunk over the same batch and output buffer as a
+ * CONDITIONAL launch on the same stream: its workgroups read the word first and leave (~2 us) unless it holds that number.
+ * So the output buffer always ends up holding what the reference's fp32 arithmetic computes (modulated_siren.py:215-233)
+ * -- identical semantics, no error to handle, nothing invalidated.  msiren_range_events: synchronising calls that found a
+ * conditional launch had run, since msiren_create (informational: such a model is better served by MSIREN_PREC_F32). */
 MSIREN_API int msiren_range_events(msiren_handle h, int64_t* count);
 /* Diagnostic: the rate the device sustains on nothing but the split-fp16 trunk's MFMA stream (v_mfma_f32_16x16x32_f16, one wave
  * per SIMD on every CU, the trunk's three products per k-step on operands of the trunk's magnitudes), ~10 ms.  *tflops: fp16

@@ -97,6 +97,7 @@ PROTOTYPES = {
     "msiren_profile_read_kernel": (C.c_int, [_vp, _i32, C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "msiren_last_trunk_kernel": (C.c_int, [_vp, C.c_char_p]),
     "msiren_device_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_uint64)]),
+    "msiren_device_pci": (C.c_int, [_vp, C.c_char_p]),
     "msiren_flops_per_coord": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "msiren_range_events": (C.c_int, [_vp, C.POINTER(_i64)]),
     "msiren_mfma_sustained_probe": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -123,7 +124,8 @@ class MsirenError(RuntimeError):
 
 
 class MsirenRangeError(MsirenError, FloatingPointError):
-    """E_RANGE: an operand left the domain of the split-fp16 trunk (see include/msiren.h, msiren_range_events)."""
+    """E_RANGE: an operand left the domain of the split-fp16 trunk.  Kept for source compatibility: since round 4 the library
+    re-runs such launches on the exact-fp32 trunk on the stream itself and never returns the code (include/msiren.h, "Domain guard")."""
 
 
 def build(verbose: bool = False) -> str:

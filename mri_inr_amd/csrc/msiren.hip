@@ -102,8 +102,9 @@ struct msiren_ctx {
     // f16x3 domain guard: a word in host memory the trunk kernels set when a scaled modulation does not fit fp16
     volatile int* status_host = nullptr;
     int* status_dev = nullptr;
-    bool f16_off = false;          // the call in flight is the exact-fp32 re-run of a host-pointer call
-    int64_t range_events = 0;      // launches that raised the flag (re-run or reported) since create
+    int range_epoch = 0;           // number of the split-fp16 trunk launch in flight (what it writes to its stream's flag word)
+    int cond_rerun = 1;            // MSIREN_RANGE_RERUN=0 (A/B knob: what the conditional launch costs): f16x3 launches go unguarded
+    int64_t range_events = 0;      // synchronisations that found the conditional exact-fp32 trunk had run, since create
     float* d_dump = nullptr;       // 256 floats: where lanes of the weight-stationary trunk that have nothing to store write
     int trace_host = 0;            // MSIREN_TRACE_HOST=1: msiren_forward_tiles prints the host-side timeline of the call (stderr)
     int host_first_pct = 50;       // MSIREN_HOST_SPLIT: share (percent) of the batch in the first of the two chunks of a host call
@@ -620,7 +621,8 @@ int queue_for_launch(msiren_ctx* h, int64_t npasses, int** counter, unsigned* ba
         if (rc) return rc;
         // test knob: start the never-reset counter just below 2^32 (or 2^31) to exercise its wrap-around
         const unsigned start = h->queue_start;
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c.queue.p, (int)start, 64, c.s));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c.queue.p, (int)start, 16, c.s));          // [0..15]: the pass counter's line
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)((int*)c.queue.p + 16), 0, 48, c.s));     // [16]: the domain guard's flag word
         c.pq.reset(start);
     }
     *counter = (int*)c.queue.p;
@@ -699,7 +701,6 @@ int launch_trunk_f16x3w(msiren_ctx* h, const float* mods_dev, int64_t B, float* 
     p.P = h->P;
     p.L = h->L;
     p.plan = h->plan;
-    p.status = h->status_dev;
     const int upp = (h->P + 31) / 32;
     const int64_t units = B * upp;
     if (units > 0x3fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
@@ -717,6 +718,8 @@ int launch_trunk_f16x3w(msiren_ctx* h, const float* mods_dev, int64_t B, float* 
     const msiren::WsSchedule sch = msiren::ws_schedule(units, grid);
     int rc = queue_for_launch(h, sch.npasses(), &p.pass_counter, &p.pass_base);
     if (rc) return rc;
+    p.status = p.pass_counter + 16;  // the stream's flag word, behind the pass counter's line
+    p.status_val = h->range_epoch;
     const int lds = msiren::WsLds<4>::total(h->L);
     const bool mor = h->cfg.activation == MSIREN_ACT_MORLET;
     using Kern = void (*)(msiren::TrunkWsParams);
@@ -765,7 +768,6 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     p.P = h->P;
     p.L = h->L;
     p.plan = h->plan;
-    p.status = h->status_dev;
     const int upp = (h->P + 31) / 32;
     const int64_t units = B * upp;
     if (units > 0x3fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
@@ -789,6 +791,8 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
         const int grid = (int)std::min<int64_t>(cus, passes);
         int rc = queue_for_launch(h, passes, &p.pass_counter, &p.pass_base);
         if (rc) return rc;
+        p.status = p.pass_counter + 16;  // the stream's flag word, behind the pass counter's line
+        p.status_val = h->range_epoch;
         if (half) return queue_launched(h, r4 ? launch_trunk_f16x3h_r<4>(h, p, grid) : launch_trunk_f16x3h_r<3>(h, p, grid));
         return queue_launched(h, r4 ? launch_trunk_f16x3n_r<4>(h, p, grid) : launch_trunk_f16x3n_r<3>(h, p, grid));
     };
@@ -863,7 +867,7 @@ int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int gr
 }
 
 bool use_f16x3(msiren_ctx* h) {
-    return !h->f16_off && h->cfg.precision == MSIREN_PREC_F16X3 && h->f16x3_ready && !h->cfg.residual &&
+    return h->cfg.precision == MSIREN_PREC_F16X3 && h->f16x3_ready && !h->cfg.residual &&
            msiren::F16Lds<3>::total(h->L) <= 160 * 1024;
 }
 
@@ -900,6 +904,30 @@ int profile_end(msiren_ctx* h, hipEvent_t end_event, int64_t coords) {
     return 0;
 }
 
+// Behind every split-fp16 trunk launch, on the same stream: the exact-fp32 trunk over the same batch as a conditional launch
+// (siren_trunk_f32_cond_kernel: 32 KB of LDS, <= 96 registers, so that it fits beside a register-resident trunk of the other
+// stream) -- its <= 2 workgroups per CU read the stream's flag word and leave unless the f16x3 launch
+// wrote its number there (a scaled modulation beyond fp16, a NaN / inf).  So the output buffer always holds what the
+// reference's fp32 arithmetic computes (modulated_siren.py:215-233), on the asynchronous API as well; the flag in host memory is
+// informational (msiren_range_events).
+int launch_trunk_f32_cond(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
+    auto& c = h->sc[h->cur];
+    const int cpp = (h->P + 31) / 32;
+    if (B * (int64_t)cpp > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
+    msiren::TrunkParams p = make_trunk_params(h, mods_dev, h->H, B, out_dev);  // (f16x3 needs H = 256 = HP: no padding of the rows)
+    p.cond = (const int*)c.queue.p + 16;
+    p.cond_val = h->range_epoch;
+    p.items = (int)(B * cpp);
+    p.host_flag = h->status_dev;
+    const int grid = (int)std::min<int64_t>(p.items, 2 * (int64_t)h->num_cus);
+    if (h->cfg.activation == MSIREN_ACT_MORLET)
+        hipLaunchKernelGGL(msiren::siren_trunk_f32_cond_kernel<1>, dim3(grid), dim3(256), 0, c.s, p);
+    else
+        hipLaunchKernelGGL(msiren::siren_trunk_f32_cond_kernel<0>, dim3(grid), dim3(256), 0, c.s, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     if (B == 0) return 0;
     if (use_f16x3(h) || h->x1_ready) {
@@ -908,9 +936,11 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
             int rc = profile_begin(h, &e1);
             if (rc) return rc;
         }
+        if (!h->x1_ready && ++h->range_epoch <= 0) h->range_epoch = 1;  // this launch's number (never 0: the flag word's rest state)
         int rc = h->x1_ready ? launch_trunk_x1(h, mods_dev, B, out_dev) : launch_trunk_f16x3(h, mods_dev, B, out_dev);
         if (rc) return rc;
-        return profile_end(h, e1, B * h->P);
+        if ((rc = profile_end(h, e1, B * h->P))) return rc;
+        return (h->x1_ready || !h->cond_rerun) ? 0 : launch_trunk_f32_cond(h, mods_dev, B, out_dev);
     }
     const int chunks = (h->P + 63) / 64;
     if (B * (int64_t)chunks > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
@@ -1078,7 +1108,7 @@ int forward_latent_dev(msiren_ctx* h, const float* z_dev, int64_t B, float* out_
 // stay on the stream that produces and consumes them.  The call still "happens on its stream": inputs are read and
 // outputs written by work that the stream's tail depends on.
 bool use_split(msiren_ctx* h, int64_t B) {
-    return h->split_min > 0 && B >= h->split_min && (h->nstreams == 1 || h->solo) && !h->plan && !h->overlap && !h->f16_off && h->L == 5 && use_f16x3(h) &&
+    return h->split_min > 0 && B >= h->split_min && (h->nstreams == 1 || h->solo) && !h->plan && !h->overlap && h->L == 5 && use_f16x3(h) &&
            !h->x1_ready && h->have_encoder && h->have_modulator && h->Z % 16 == 0 && ws_capable(h, B);
 }
 
@@ -1126,7 +1156,7 @@ int forward_tiles_dev(msiren_ctx* h, const float* tiles_dev, int64_t B, float* o
     return launch_trunk(h, mods, B, out_dev);
 }
 
-// the f16x3 domain guard's flag: set by a trunk launch that met a scaled modulation beyond fp16 (or a NaN / inf)
+// the f16x3 domain guard's flag in host memory: raised by a conditional exact-fp32 trunk launch that had to run
 bool take_range_flag(msiren_ctx* h) {
     if (!h->status_host || !*h->status_host) return false;
     *h->status_host = 0;
@@ -1137,25 +1167,16 @@ bool take_range_flag(msiren_ctx* h) {
 int sync_all(msiren_ctx* h) {
     for (auto& c : h->sc)
         if (c.s) HIPCHK(hipStreamSynchronize(c.s));
-    if (!h->f16_off && take_range_flag(h))
-        return fail(MSIREN_E_RANGE, "a modulation (times the layer's power-of-two weight scale) exceeds what the split-fp16 trunk's fp16 "
-                                    "operands can carry (65504), or is not finite: the outputs of the calls since the last sync are not valid. "
-                                    "Use precision=\"fp32\" (MSIREN_PREC_F32) for this model, or the host-pointer entry points, which re-run such a "
-                                    "call on the exact-fp32 trunk by themselves");
+    (void)take_range_flag(h);  // informational: the outputs are the exact-fp32 trunk's already
     return 0;
 }
 
-// Host-pointer (synchronous) calls: a call that raised the flag is run again on the exact-fp32 trunk -- still the HIP path,
-// 3x slower, right -- so that precision "auto" never returns inf / NaN where the reference's fp32 would not.
+// Host-pointer (synchronous) calls.  (Until round 3 a call whose f16x3 trunk raised the domain flag was run again on the
+// exact-fp32 trunk from here; since round 4 the re-run is a conditional launch on the stream itself, for every entry point.)
 template <typename F>
 int with_range_fallback(msiren_ctx* h, F&& run) {
-    int rc = run();
-    if (rc == MSIREN_E_RANGE || (rc == 0 && take_range_flag(h))) {
-        h->f16_off = true;
-        rc = run();
-        h->f16_off = false;
-        (void)take_range_flag(h);
-    }
+    const int rc = run();
+    (void)take_range_flag(h);
     return rc;
 }
 
@@ -1335,6 +1356,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_HOST_CHUNKS")) h->host_chunks = std::max(1, std::min(std::atoi(e), 16));
     if (const char* e = std::getenv("MSIREN_QUEUE_START")) h->queue_start = (unsigned)std::strtoul(e, nullptr, 0);
     if (const char* e = std::getenv("MSIREN_F16_WS")) h->f16_ws = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_RANGE_RERUN")) h->cond_rerun = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_SPLIT_MIN")) h->split_min = std::max<long long>(0, std::atoll(e));
     if (const char* e = std::getenv("MSIREN_LINEAR_TILE_MIN")) h->lin_tile_min = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("MSIREN_SPLIT_PCT")) h->split_pct = std::max(1, std::min(90, std::atoi(e)));
@@ -1935,6 +1957,14 @@ int msiren_device_info(msiren_handle h, char* name256, int32_t* cus, int32_t* mh
     if (cus) *cus = prop.multiProcessorCount;
     if (mhz) *mhz = prop.clockRate / 1000;
     if (hbm) *hbm = (uint64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+int msiren_device_pci(msiren_handle h, char* busid32) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (!busid32) return fail(MSIREN_E_INVALID, "null argument");
+    HIPCHK(hipDeviceGetPCIBusId(busid32, 32, h->cfg.device));
     return 0;
 }
 

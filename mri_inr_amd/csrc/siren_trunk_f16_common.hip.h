@@ -37,7 +37,8 @@ struct TrunkF16Params {
     int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
     unsigned pass_base;        // value of *pass_counter when this launch starts (arithmetic is modulo 2^32)
     unsigned long long* stamps; // diagnostic instantiation only: [grid][8 passes][8] s_memtime + realtime
-    int* status;              // domain guard: set to 1 when a scaled modulation does not fit fp16 (host-mapped word; may be null)
+    int* status;              // domain guard: the stream's flag word (device memory; may be null) -- a launch that meets a scaled
+    int status_val;           // modulation that does not fit fp16 writes its own number there (read by the conditional fp32 launch behind it)
 };
 
 constexpr int F16_CHUNK_BYTES = 32768;

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3h_kernel(TrunkF16Para
             bad_mod |= f16_out_of_range(ms);
             *reinterpret_cast<f32x4*>(modT + l * 256 + lane * 4) = ms;
         }
-        if (bad_mod && p.status) *p.status = 1;
+        if (bad_mod && p.status) *p.status = p.status_val;
         if (tid == 0) qslot[(pass + 1) & 1] = nxt;
 
         // layer 0 from the table: k-steps 0..6 finished here, the last 32 features wait in acc[1] for the first hidden

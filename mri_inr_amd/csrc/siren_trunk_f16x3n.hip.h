@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_f16x3n_kernel(TrunkF16Para
             bad_mod |= f16_out_of_range(ms);
             *reinterpret_cast<f32x4*>(modT + l * 256 + lane * 4) = ms;
         }
-        if (bad_mod && p.status) *p.status = 1;
+        if (bad_mod && p.status) *p.status = p.status_val;
         if (tid == 0) qslot[(pass + 1) & 1] = nxt;  // read after >= 32 workgroup barriers
 
         // ---- layer 0 (K = 2) from the per-weight-set table act0(W0 x_p + b0), directly in B-operand order:

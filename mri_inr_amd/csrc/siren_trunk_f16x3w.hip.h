@@ -98,7 +98,8 @@ struct TrunkWsParams {
     int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
     unsigned pass_base;
     unsigned long long* stamps;
-    int* status;              // domain guard (f16_out_of_range): host-mapped word, may be null
+    int* status;              // domain guard (f16_out_of_range): the stream's flag word (device memory), may be null
+    int status_val;           // what a launch that meets an out-of-range modulation writes there: its own number
 };
 
 template <int NB>
@@ -133,6 +134,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     const unsigned npasses = (unsigned)sch.npasses();
     int cur_pass = (int)blockIdx.x;
     if ((unsigned)cur_pass >= npasses) return;
+    // diagnostic instance: launch-level marks, s_memrealtime (100 MHz, comparable across CUs) in entry [7] of the workgroup's
+    // first three slot records: [0][7] workgroup entry, [1][7] prologue done (first MFMA next), [2][7] workgroup done
+    auto mark = [&](int which) {
+        if constexpr (DBG) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            if (threadIdx.x == 0) p.stamps[((size_t)blockIdx.x * 96 + which) * 8 + 7] = t;
+        }
+    };
+    mark(0);
 
     // ---- per-lane bases (every LDS access below is base + compile-time constant, or + one per-slot scalar) -----------
     unsigned char* const actL = smem + LY::act + lane * 16;                       // + unit * 32768 + fragment offset
@@ -142,14 +152,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     float* const redW = reinterpret_cast<float*>(smem + LY::red(L));              // [parity][coordinate 0..31][wave]
     int* const qslot = reinterpret_cast<int*>(smem + LY::queue(L));  // (plain LDS accesses: a volatile one became a flat op + vmcnt(0))
     float* const mscaleT = reinterpret_cast<float*>(smem + LY::mscale(L));
-
-    // ---- once per workgroup: constant tables ----------------------------------------------------------------------
-    {
-        float* bw = reinterpret_cast<float*>(smem + LY::bias);
-        for (int i = tid; i < (L - 1) * 256; i += 256) bw[i] = p.bias[i];
-        reinterpret_cast<float*>(smem + LY::wout(L))[tid] = p.wout[tid];
-        if (tid < 16) mscaleT[tid] = p.mscale[tid];
-    }
 
     // pass id -> (first unit, number of units)
     auto pass_units = [&](int id, int& u0, int& nb) {
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         rb = rb >= NR ? rb - NR : rb;
         rb = rb >= NR ? rb - NR : rb;
         f32x4 ma = m[0] * msc0, mb = m[1] * msc1;
-        if ((f16_out_of_range(ma) || f16_out_of_range(mb)) && p.status) *p.status = 1;  // (clamped rows repeat a checked one)
+        if ((f16_out_of_range(ma) || f16_out_of_range(mb)) && p.status) *p.status = p.status_val;  // (clamped rows repeat a checked one)
         // the final layer's row only ever meets last_layer.weight (its scale is 1): the table holds the product
         if (q == L - 1) ma *= wrow;
         if (4 + q == L - 1) mb *= wrow;
@@ -342,7 +344,18 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         }
     };
 
-    // ---- prologue (once per workgroup, not overlapped): layer-1 weights, tables and layer 0 of the first pass ---------
+    // ---- prologue (once per workgroup, not overlapped): constant tables, layer-1 weights, layer 0 of the first pass ---
+    // 7.2 us of a 273 us single-slice launch (tools/timeline_ws_launch.py, profiles/r4/): 2.6 %.  Round 4 rebuilt it so that
+    // everything -- modulation rows of all units, weights, queue atomic, layer-0 table values, constant tables -- was in
+    // flight before anything was waited for (one dependent memory round trip instead of ten): same bits, 7.3 us, launch
+    // 0.2731 against 0.2736 ms same-box (profiles/r4/): the round trips were not what the prologue is made of, and this
+    // simpler form stayed.
+    {
+        float* bw = reinterpret_cast<float*>(smem + LY::bias);
+        for (int i = tid; i < (L - 1) * 256; i += 256) bw[i] = p.bias[i];
+        reinterpret_cast<float*>(smem + LY::wout(L))[tid] = p.wout[tid];
+        if (tid < 16) mscaleT[tid] = p.mscale[tid];
+    }
     {
         const unsigned char* wb = wlayer(1);
         MSIREN_WS_LOADK(0, wb); MSIREN_WS_LOADK(1, wb); MSIREN_WS_LOADK(2, wb); MSIREN_WS_LOADK(3, wb);
@@ -394,6 +407,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     int fin_par = 0;  // which half of the reduction buffer the final slot in flight uses
 
     const unsigned char* wnext = wlayer(1);  // weight base of the layer to fetch during this slot (a layer's last unit)
+    mark(1);
 
     // first fragments + bias of the first slot
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -813,6 +827,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mark(2);
     MSIREN_WS_HOLD();
 #undef MSIREN_WS_HOLD
 #undef MSIREN_WS_SLOT

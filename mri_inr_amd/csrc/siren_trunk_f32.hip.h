@@ -44,6 +44,11 @@ struct TrunkParams {
     int B, P, L, mod_stride, chunks;
     unsigned long long* stamps;  // diagnostic build only: [grid][32] s_memtime stamps
     const int* plan;     // optional (compact_flags_kernel): only patches b < plan[0] are evaluated
+    // conditional instance only (siren_trunk_f32_cond_kernel): run iff *cond == cond_val, over `items` (patch, chunk)
+    // work items; when it runs it raises *host_flag (a word in host memory, informational)
+    const int* cond;
+    int cond_val, items;
+    int* host_flag;
 };
 
 // sin(2*pi*r) with the hardware sine, whose argument is in revolutions.  On gfx950 v_sin_f32 performs
@@ -61,10 +66,20 @@ __device__ __forceinline__ float activate(float r, float cg) {
     }
 }
 
+// last_layer's partial sum over four features, part + ((a0 m0 + a1 m1) + (a2 m2 + a3 m3)), with the multiply-adds SPELLED OUT:
+// left to the compiler, a * b + c is fused or not depending on the shape of the surrounding code, and two kernels that
+// must give the same bits (siren_trunk_f32_kernel and its conditional stand-in behind the f16x3 trunks) would differ.
+__device__ __forceinline__ float dot4_acc(float part, const f32x4 a, const f32x4 m) {
+    const float s01 = __builtin_fmaf(a[1], m[1], a[0] * m[0]);
+    const float s23 = __builtin_fmaf(a[3], m[3], a[2] * m[2]);
+    return part + (s01 + s23);
+}
+
 // DBG = 1 is a separate diagnostic instantiation (msiren_trunk_timeline): wave 0 of every workgroup
 // stamps s_memtime at each phase boundary into p.stamps; the shipped kernel (DBG = 0) has no stamps.
-template <int HP, int ACT, int RES, int DBG = 0>
-__global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kernel(TrunkParams p) {
+// One work item = (patch, chunk of 64 coordinates) = `item`; the kernels below are the callers.
+template <int HP, int ACT, int RES, int DBG>
+__device__ __forceinline__ void siren_trunk_f32_item(const TrunkParams& p, const int item) {
     constexpr int TT = HP / 128;  // 32-feature tiles per wave
     constexpr int QN = HP / 8;    // k-blocks of 8 per layer (16*TT/2 MFMAs each)
     constexpr int KG = HP / 4;    // k-groups of 4 (rows of the X image)
@@ -78,15 +93,15 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
     const int c32 = lane & 31;
-    const int b = blockIdx.x / p.chunks;
-    const int ch = blockIdx.x - b * p.chunks;
+    const int b = item / p.chunks;
+    const int ch = item - b * p.chunks;
     if (p.plan && b >= p.plan[0]) return;  // workgroup-uniform, before any barrier
     const int L = p.L;
     int nstamp = 0;
     auto stamp = [&]() {
         if constexpr (DBG) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if (tid == 0 && nstamp < 28) p.stamps[(size_t)blockIdx.x * 32 + 4 + nstamp] = t;
+            if (tid == 0 && nstamp < 28) p.stamps[(size_t)item * 32 + 4 + nstamp] = t;
             ++nstamp;
         }
     };
@@ -96,10 +111,10 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(ldsa));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            p.stamps[(size_t)blockIdx.x * 32 + 0] = hwid;
-            p.stamps[(size_t)blockIdx.x * 32 + 1] = ldsa;
-            p.stamps[(size_t)blockIdx.x * 32 + 2] = xcc;
-            p.stamps[(size_t)blockIdx.x * 32 + 3] = __builtin_amdgcn_s_memrealtime();
+            p.stamps[(size_t)item * 32 + 0] = hwid;
+            p.stamps[(size_t)item * 32 + 1] = ldsa;
+            p.stamps[(size_t)item * 32 + 2] = xcc;
+            p.stamps[(size_t)item * 32 + 3] = __builtin_amdgcn_s_memrealtime();
         }
     }
     stamp();  // 0: start
@@ -273,17 +288,22 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
                     if constexpr (RES) wo = *reinterpret_cast<const f32x4*>(p.wout + fwave + 32 * tt + 8 * g + 4 * half);
 #pragma unroll
                     for (int jc = 0; jc < 2; ++jc) {
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float r = acc[tt][jc][4 * g + e] + bias_r[tt][g][e];
-                            v[e] = activate<ACT>(r, p.cg) * mod_r[tt][g][e];
-                        }
                         if constexpr (RES) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float r = acc[tt][jc][4 * g + e] + bias_r[tt][g][e];
+                                v[e] = activate<ACT>(r, p.cg) * mod_r[tt][g][e];
+                            }
                             v += X[(kgw + 8 * tt + 2 * g + half) * 64 + 32 * jc + c32];
                             v *= wo;
+                            part[jc] += (v[0] + v[1]) + (v[2] + v[3]);
+                        } else {
+                            f32x4 av;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) av[e] = activate<ACT>(acc[tt][jc][4 * g + e] + bias_r[tt][g][e], p.cg);
+                            part[jc] = dot4_acc(part[jc], av, mod_r[tt][g]);  // (mod_r holds modulation x last_layer.weight here)
                         }
-                        part[jc] += (v[0] + v[1]) + (v[2] + v[3]);
                     }
                 }
         }
@@ -321,7 +341,143 @@ __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kern
     }
     stamp();  // end
     if constexpr (DBG) {
-        if (tid == 0) p.stamps[(size_t)blockIdx.x * 32 + 31] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) p.stamps[(size_t)item * 32 + 31] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+template <int HP, int ACT, int RES, int DBG = 0>
+__global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kernel(TrunkParams p) {
+    siren_trunk_f32_item<HP, ACT, RES, DBG>(p, (int)blockIdx.x);
+}
+
+// The exact-fp32 trunk (H = 256) as a CONDITIONAL launch behind a split-fp16 trunk launch on the same stream: the f16x3
+// kernels write their launch's number to *cond when a scaled modulation does not fit their fp16 operands
+// (f16_out_of_range); every workgroup of this kernel reads the word first and leaves if it does not hold that number -- the
+// normal case, a couple of microseconds for the launch.  Otherwise its (few, persistent) workgroups evaluate all `items`
+// = (patch, chunk of 32 coordinates) into the same output buffer: the buffer always ends up holding what the reference's
+// fp32 arithmetic computes (modulated_siren.py:215-233), whatever the modulations.
+//
+// Small on purpose -- 32 KB of LDS, <= 96 registers -- so that it is dispatched BESIDE a persistent register-resident trunk
+// of the handle's other stream (which leaves 34 KB / 112 registers per CU; the 64-coordinate kernel above needs 68 KB and
+// would sit in front of its stream until that trunk has left every CU: measured -12 % on the two-stream pipeline).  Speed
+// when it does run is secondary; what matters is that it produces THE BITS OF siren_trunk_f32_kernel<256, ACT, 0>: the same
+// v_mfma_f32_32x32x2_f32 on the same k pairs in the same order per accumulator, the same layer-0 FMAs, the same epilogue
+// expressions, the same order of the last_layer sum (tests/test_gpu_ws.py: np.array_equal against the fp32 model).
+template <int ACT>
+__global__ __launch_bounds__(256, 5) void siren_trunk_f32_cond_kernel(TrunkParams p) {
+    if (__builtin_amdgcn_readfirstlane(*p.cond) != p.cond_val) return;
+    constexpr int HP = 256, TT = 2, QN = HP / 8, KG = HP / 4;
+    __shared__ f32x4 X[KG * 32];  // X[kg * 32 + coord]: features 4 kg .. 4 kg + 3 of the chunk's 32 coordinates
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int c32 = lane & 31;
+    const int L = p.L;
+    if (blockIdx.x == 0 && tid == 0 && p.host_flag) *p.host_flag = 1;
+    const int cpp = (p.P + 31) / 32;  // chunks per patch
+    const int fwave = wave * 64, kgw = wave * 16;
+    const f32x4* wbase = reinterpret_cast<const f32x4*>(p.wp) + lane;
+    for (int item = (int)blockIdx.x; item < p.items; item += (int)gridDim.x) {
+        const int b = item / cpp, ch = item - b * cpp;
+        if (p.plan && b >= p.plan[0]) break;  // workgroup-uniform; items are in patch order
+        int pc = ch * 32 + c32;
+        pc = pc < p.P ? pc : p.P - 1;
+        const float2 xy = reinterpret_cast<const float2*>(p.grid)[pc];
+        {   // layer 0 (K = 2): this wave's 16 rows of the image, two rows (one per half-wave) at a time
+            const f32x4* l0 = reinterpret_cast<const f32x4*>(p.l0);
+            const float* mod0 = p.mods + (size_t)b * p.mod_stride;
+            for (int i = 0; i < 8; ++i) {
+                const int kg = kgw + 2 * i + half;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 w = l0[4 * kg + e];
+                    const float r = __builtin_fmaf(xy.y, w.y, __builtin_fmaf(xy.x, w.x, w.z));
+                    v[e] = activate<ACT>(r, p.cg0) * mod0[4 * kg + e];
+                }
+                X[kg * 32 + c32] = v;
+            }
+        }
+        __syncthreads();
+        float part = 0.f;
+        for (int l = 1; l < L; ++l) {
+            const float* bl = p.bias + (size_t)(l - 1) * HP;
+            const float* ml = p.mods + ((size_t)l * p.B + b) * p.mod_stride;
+            const bool last = (l == L - 1);
+            f32x16 acc[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+            for (int q = 0; q < QN; ++q) {
+                const f32x4* ptr = wbase + (((size_t)(l - 1) * 4 + wave) * QN + q) * (TT * 64);
+                const f32x4 a0 = ptr[0], a1 = ptr[64];
+                const f32x4 bb = X[(2 * q + half) * 32 + c32];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bb[j], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bb[j], acc[1], 0, 0, 0);
+                }
+            }
+            __syncthreads();  // every wave has finished reading X: rows may now be overwritten
+            // (two separate branches with the expressions of siren_trunk_f32_item, so that the compiler contracts -- or does not
+            //  contract -- the same multiply-adds in both kernels: the results must be the same BITS)
+            if (!last) {
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int fo = fwave + 32 * tt + 8 * g + 4 * half;
+                        const f32x4 bias_r = *reinterpret_cast<const f32x4*>(bl + fo);
+                        const f32x4 mod_r = *reinterpret_cast<const f32x4*>(ml + fo);
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float r = acc[tt][4 * g + e] + bias_r[e];
+                            v[e] = activate<ACT>(r, p.cg) * mod_r[e];
+                        }
+                        X[(kgw + 8 * tt + 2 * g + half) * 32 + c32] = v;
+                    }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int fo = fwave + 32 * tt + 8 * g + 4 * half;
+                        const f32x4 bias_r = *reinterpret_cast<const f32x4*>(bl + fo);
+                        f32x4 mod_r = *reinterpret_cast<const f32x4*>(ml + fo);
+                        mod_r *= *reinterpret_cast<const f32x4*>(p.wout + fo);
+                        f32x4 av;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) av[e] = activate<ACT>(acc[tt][4 * g + e] + bias_r[e], p.cg);
+                        part = dot4_acc(part, av, mod_r);
+                    }
+            }
+            if (!last) __syncthreads();
+        }
+        // last_layer: dot over the 256 features, always sine
+        float* red = reinterpret_cast<float*>(X);  // [4][32]; X is dead (the barrier behind the last K loop)
+        if (L == 1) {
+            float s = 0.f;
+            for (int i = 0; i < 8; ++i) {
+                const int kg = kgw + 2 * i + half;
+                const f32x4 v = X[kg * 32 + c32];
+                const f32x4 wo = *reinterpret_cast<const f32x4*>(p.wout + 4 * kg);
+                s += v[0] * wo[0] + v[1] * wo[1] + v[2] * wo[2] + v[3] * wo[3];
+            }
+            part = s;
+            __syncthreads();
+        }
+        part += __shfl_xor(part, 32);
+        if (half == 0) red[wave * 32 + c32] = part;
+        __syncthreads();
+        if (tid < 32) {
+            const float s = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid] + p.bout;
+            const int po = ch * 32 + tid;
+            if (po < p.P) p.out[(size_t)b * p.P + po] = sin_rev(s);
+        }
+        __syncthreads();  // the next item reuses the image
     }
 }
 

@@ -166,6 +166,14 @@ class RcclGroup:
     def min(self, value: float) -> float:
         return -self.max(-float(value))
 
+    def max_array(self, values) -> list:
+        """Element-wise MAX over the ranks of a short list of floats (one msiren_comm_allreduce_max_f64)."""
+        from . import _lib
+
+        v = (C.c_double * len(values))(*[float(x) for x in values])
+        _lib.check(self._lib.msiren_comm_allreduce_max_f64(self._h, v, len(values)))
+        return [float(x) for x in v]
+
     def destroy(self):
         from . import _lib
 

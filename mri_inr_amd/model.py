@@ -481,7 +481,10 @@ class ModulatedSiren:
         name = C.create_string_buffer(256)
         cus, mhz, hbm = C.c_int32(), C.c_int32(), C.c_uint64()
         _lib.check(self._lib.msiren_device_info(self._h, name, C.byref(cus), C.byref(mhz), C.byref(hbm)))
-        return dict(name=name.value.decode(), compute_units=cus.value, clock_mhz=mhz.value, hbm_bytes=hbm.value)
+        pci = C.create_string_buffer(32)
+        _lib.check(self._lib.msiren_device_pci(self._h, pci))
+        return dict(name=name.value.decode(), compute_units=cus.value, clock_mhz=mhz.value, hbm_bytes=hbm.value,
+                    pci_bus_id=pci.value.decode(), device_index=self._device)
 
     def flops_per_coord(self) -> float:
         H, L = self.dim_hidden, self.num_layers

@@ -63,6 +63,36 @@ def test_spawn_ranks_kills_survivors_of_a_failed_rank(tmp_path):
     assert rc == 3  # returned promptly: the sleeping rank was terminated
 
 
+def test_rank_dying_inside_the_broadcast_takes_the_job_down_within_30_s(tmp_path):
+    """After the bootstrap every rank sits in the weight broadcast -- a native call that returns only when all ranks have
+    joined.  If one dies there (a GPU fault, an OOM kill), the others would wait for ever: the launcher must end the job,
+    also when a survivor does not react to SIGTERM (blocked in native code with the signal ignored -> SIGKILL after 10 s)."""
+    p = tmp_path / "bcast.py"
+    p.write_text(textwrap.dedent("""
+        import ctypes, os, signal, sys
+        sys.path.insert(0, %r)
+        from mri_inr_amd.launch import exchange_from_rank0
+        r = int(os.environ["RANK"])
+        exchange_from_rank0(b"id" if r == 0 else None, timeout=60)      # the bootstrap succeeds on every rank
+        print("rank", r, "enters the broadcast", file=sys.stderr, flush=True)
+        if r == 2:
+            os.kill(os.getpid(), signal.SIGKILL)                        # dies inside the collective
+        if r == 1:
+            signal.signal(signal.SIGTERM, signal.SIG_IGN)               # a survivor that cannot be asked nicely
+        ctypes.CDLL(None).sleep(600)                                    # blocked in native code, like ncclBroadcast
+    """) % ROOT)
+    err = io.StringIO()
+    t0 = time.monotonic()
+    rc, _ = launch.spawn_ranks([sys.executable, str(p)], 3, timeout=300, stdout=io.StringIO(), stderr=err)
+    took = time.monotonic() - t0
+    assert rc != 0 and took < 30, (rc, took)
+    assert err.getvalue().count("enters the broadcast") == 3
+    # nothing is left behind
+    time.sleep(0.2)
+    out = subprocess.run(["pgrep", "-f", str(p)], capture_output=True, text=True).stdout.split()
+    assert out == [], out
+
+
 def test_under_launcher_and_single_rank_exchange():
     assert not launch.under_launcher({})
     assert launch.under_launcher({"RANK": "0", "WORLD_SIZE": "2"})

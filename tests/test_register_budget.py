@@ -23,6 +23,8 @@ TU = r"""
 template __global__ void msiren::siren_trunk_f16x3n_kernel<0, 3, 5>(msiren::TrunkF16Params);
 template __global__ void msiren::siren_trunk_f16x3n_kernel<1, 3, 5>(msiren::TrunkF16Params);
 template __global__ void msiren::linear_mfma_tile_kernel<2, 2>(msiren::ModulatorMfmaParams);
+template __global__ void msiren::siren_trunk_f32_cond_kernel<0>(msiren::TrunkParams);
+template __global__ void msiren::siren_trunk_f32_cond_kernel<1>(msiren::TrunkParams);
 """
 
 
@@ -50,6 +52,7 @@ def _usage(tmp_path):
 def test_trunk_and_its_neighbours_fit_on_one_cu(tmp_path):
     usage = _usage(tmp_path)
     trunks = {k: v for k, v in usage.items() if "siren_trunk_f16x3" in k}
+    assert sum("siren_trunk_f32_cond" in k for k in usage) == 2   # the conditional exact-fp32 launch runs beside the other stream's trunk
     beside = {k: v for k, v in usage.items() if k not in trunks}
     assert len(trunks) == 2 and len(beside) >= 8 and any("linear_mfma_tile" in k for k in beside), list(usage)  # the register-resident 16x16x32 trunk, sine / Morlet
 
