@@ -598,7 +598,7 @@ def main():
                 # behind the timed region: never `value`
                 for d in (d_img, d_tiles, *d_outs, *d_recons):
                     d.free()
-                result["extra"]["configs"] = other_configs(sd, model, sustained_tflops)
+                result["extra"]["configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline and not deep:
             result["cpu_baseline"] = cpu_baseline(sd, tiles400, args.activation, args.cpu_seconds)
         else:
@@ -685,109 +685,53 @@ def scaling_selftest(args) -> int:
     return 0 if ok else 1
 
 
-def side_measure(model, n_slices, streams, steps, warmup, peak, seconds=0.25):
-    """One configuration beside the headline: `steps` timed msiren_forward_tiles_dev calls of n_slices x 400 resident tiles
-    (after `warmup` calls and until the card has been busy for `seconds`), then -- if streams == 2 -- a one-stream phase
-    for the kernel alone.  Returns value / ms per step / the trunk instances the library launched with their rates."""
-    from mri_inr_amd import _lib, synthetic as syn
+def other_configs(launch_timeout=300.0):
+    """BASELINE.json configs 3, 4, 5 and the exact-fp32 trunk at N = 1, each measured by THIS script in a child process of its
+    own behind the headline's timed region (device-resident tiles, random-init weights of the named architecture; the parent
+    only waits): the numbers are those of the stand-alone commands, summarised.  (Measured in-process on further handles the
+    two-stream figures came out 8-22 % low: a process has a handful of hardware queues, and the streams of a third and fourth
+    handle share them.)"""
+    import subprocess
 
-    lib, h = model._lib, model._h
-    B = n_slices * 400
-    imgs = np.stack([syn.make_slice(k) for k in range(n_slices)])
-    d_img, d_tiles = model.device_array(imgs.shape), model.device_array((B, 32, 32))
-    d_outs = [model.device_array((B, 24, 24)) for _ in range(2)]
-    d_img.copy_from(imgs)
-    _lib.check(lib.msiren_image_to_patches_dev(h, d_img.ptr, n_slices, 320, 320, d_tiles.ptr))
-    fpc = model.flops_per_coord()
-    k = [0]
+    from mri_inr_amd import launch
 
-    def step():
-        _lib.check(lib.msiren_forward_tiles_dev(h, d_tiles.ptr, B, d_outs[k[0] & 1].ptr))
-        k[0] += 1
-
-    def phase(nstreams, n):
-        _lib.check(lib.msiren_set_streams(h, nstreams))
-        t_w = time.perf_counter()
-        for _ in range(warmup):
-            step()
-        model.sync()
-        while time.perf_counter() - t_w < seconds:
-            for _ in range(4):
-                step()
-            model.sync()
-        _lib.check(lib.msiren_profile_enable(h, 1))
-        t0 = time.perf_counter()
-        for _ in range(n):
-            step()
-        model.sync()
-        dt = time.perf_counter() - t0
-        recs = model.profile_kernels()
-        _lib.check(lib.msiren_profile_enable(h, 0))
-        ks = []
-        for r in recs:
-            tf = fpc * r["coords"] / (r["ms_total"] * 1e-3) / 1e12 if r["ms_total"] > 0 else 0.0
-            ks.append({"kernel": r["kernel"], "launches": r["launches"], "avg_launch_ms": r["ms_total"] / max(r["launches"], 1),
-                       "achieved_tflops": tf, "frac": tf / peak})
-        return dt, ks
-
-    dt, ks = phase(streams, steps)
-    timed_tf = fpc * B * 576 * steps / dt / 1e12
-    out = {"value": n_slices * 320 * 320 * steps / dt / 1e6, "unit": "Mpixel/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-           "slices_per_step": n_slices, "streams": streams, "timed_frac": timed_tf / peak, "timed_region_kernels": ks}
-    if streams == 2:
-        n1 = max(8, steps // 2)
-        dt1, ka = phase(1, n1)
-        out["kernel_alone"] = ka
-        out["one_stream"] = {"value": n_slices * 320 * 320 * n1 / dt1 / 1e6, "ms_per_step": dt1 / n1 * 1e3, "steps": n1,
-                             "timed_frac": fpc * B * 576 * n1 / dt1 / 1e12 / peak}
-    else:
-        out["kernel_alone"] = ks
-    dom = max(out["kernel_alone"], key=lambda r: r["achieved_tflops"] * r["avg_launch_ms"] * r["launches"])
-    out["kernel"], out["kernel_alone_frac"] = dom["kernel"], dom["frac"]
-    for d in (d_img, d_tiles, *d_outs):
-        d.free()
-    return out
-
-
-def other_configs(sd, model, sustained_tflops):
-    """BASELINE.json configs 3, 4, 5 and the exact-fp32 trunk at N = 1, measured in this process behind the headline's timed
-    region (device-resident tiles, as the headline; random-init weights of the named architecture)."""
-    from mri_inr_amd import ModulatedSiren, synthetic as syn
-
-    f16x3_peak = F16_MFMA_PEAK_TFLOPS / 3.0
-
-    def build(H, L, Z, act, prec, res, state):
-        m = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=1.0, w0_initial=30.0, use_bias=True,
-                           dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None, outer_patch_size=32,
-                           inner_patch_size=16, siren_patch_size=24, device=model.device_string(), activation=act,
-                           precision=prec, residual=res)
-        m.load_state_dict(state)
-        m.to(model.device_string()).eval()
-        return m
-
+    env = {k: v for k, v in os.environ.items() if k not in launch.ENV_KEYS}
+    runs = {
+        "config3_64_slices_n1": (["--total-slices", "64", "--steps", "24", "--warmup", "3"],
+                                 "BASELINE configs[2]: 64 slices = 25600 tiles per call, one GPU, two streams"),
+        "config3_64_slices_n1_one_stream": (["--total-slices", "64", "--streams", "1", "--steps", "24", "--warmup", "3"],
+                                            "the same on a one-stream handle: the call is cut in two and overlaps with itself"),
+        "config3_8_slices_per_rank": (["--slices", "8", "--steps", "120", "--warmup", "10"],
+                                      "8 slices = 3200 tiles per call: one rank's share of configs[2] on 8 GPUs"),
+        "config4_morlet": (["--activation", "morlet", "--steps", "600", "--warmup", "30"], "BASELINE configs[3]: Morlet activation, one slice per call"),
+        "fp32_trunk": (["--precision", "fp32", "--steps", "300", "--warmup", "20"],
+                       "configs[1] on the exact-fp32 trunk (v_mfma_f32_32x32x2_f32), one slice per call"),
+        "config5_deep_residual_bf16": (["--model", "deep_residual", "--precision", "bf16", "--steps", "300", "--warmup", "20"],
+                                       "BASELINE configs[4]: deep residual 10x512, latent 128, bf16 MFMA (own semantics, parity unpinned)"),
+    }
     out = {}
-    # config 3 (the scaling configuration) on ONE GPU: 64 slices per call; and 8 slices per call (one rank's share of it on 8 GPUs)
-    out["config3_64_slices_n1"] = dict(side_measure(model, 64, 2, 12, 2, f16x3_peak), dtype="f16x3", peak_tflops=f16x3_peak,
-                                       workload="BASELINE configs[2]: 64 slices = 25600 tiles per call, one GPU")
-    out["config3_8_slices_per_rank"] = dict(side_measure(model, 8, 2, 60, 5, f16x3_peak), dtype="f16x3", peak_tflops=f16x3_peak,
-                                            workload="8 slices = 3200 tiles per call: one rank's share of configs[2] on 8 GPUs")
-    m4 = build(256, 5, 256, "morlet", "f16x3", False, sd)
-    out["config4_morlet"] = dict(side_measure(m4, 1, 2, 300, 20, f16x3_peak), dtype="f16x3", peak_tflops=f16x3_peak,
-                                 workload="BASELINE configs[3]: Morlet activation, one slice per call")
-    del m4
-    m32 = build(256, 5, 256, "sine", "fp32", False, sd)
-    out["fp32_trunk"] = dict(side_measure(m32, 1, 2, 150, 10, FP32_MFMA_PEAK_TFLOPS), dtype="f32", peak_tflops=FP32_MFMA_PEAK_TFLOPS,
-                             workload="configs[1] on the exact-fp32 trunk (v_mfma_f32_32x32x2_f32), one slice per call")
-    del m32
-    sd5 = syn.make_state_dict(seed=7, dim_hidden=512, num_layers=10, latent_dim=128, modulator_bias_center=0.25, encoder_gain=10.0)
-    m5 = build(512, 10, 128, "sine", "bf16", True, sd5)
-    out["config5_deep_residual_bf16"] = dict(side_measure(m5, 1, 2, 150, 10, F16_MFMA_PEAK_TFLOPS), dtype="bf16", peak_tflops=F16_MFMA_PEAK_TFLOPS,
-                                             workload="BASELINE configs[4]: deep residual 10x512, latent 128, bf16 MFMA (own semantics, "
-                                                      "parity unpinned), one slice per call")
-    del m5
-    out["note"] = ("each entry: `value` = its own timed region (two streams, tiles resident), never the headline's; `kernel` / "
-                   "`kernel_alone_frac` = dominant trunk instance of a one-stream phase as the library names it; "
-                   "`timed_frac` = trunk FLOPs of the entry's timed region / its wall time / peak_tflops")
+    for name, (flags, what) in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-extras"] + flags
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=launch_timeout)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or len(lines) != 1:
+                out[name] = {"error": f"rc {r.returncode}: {r.stderr[-300:]}", "command": " ".join(cmd[1:])}
+                continue
+            d = json.loads(lines[0])
+        except Exception as exc:  # noqa: BLE001 -- a side measurement must not take the headline line down
+            out[name] = {"error": repr(exc), "command": " ".join(cmd[1:])}
+            continue
+        rf, ka = d["roofline"], d.get("roofline_kernel_alone") or d["roofline"]
+        out[name] = {"workload": what, "command": "bench.py " + " ".join(flags), "value": d["value"], "unit": d["unit"],
+                     "ms_per_step": d["ms_per_step"], "steps": d["steps"], "dtype": d["dtype"], "streams": d["config"]["streams"],
+                     "slices_per_step": d["config"]["slices_per_step_total"], "peak_tflops": rf["peak"],
+                     "timed_region_kernel": rf["kernel"], "timed_frac": rf["frac"],
+                     "timed_region_kernels": [{k: x[k] for k in ("kernel", "launches", "avg_launch_ms", "frac")} for x in rf["timed_region_kernels"]],
+                     "kernel": ka["kernel"], "kernel_alone_frac": ka["frac"], "kernel_alone_avg_launch_ms": ka["avg_launch_ms"]}
+    out["note"] = ("each entry: a child `bench.py` run behind the headline's timed region (`command`), never the headline's `value`; "
+                   "`kernel` / `kernel_alone_frac` = dominant trunk instance of a one-stream phase (or of the timed region when it is "
+                   "one-stream) as the library names it; `timed_frac` = the entry's own roofline.frac")
     return out
 
 

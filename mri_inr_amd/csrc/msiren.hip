@@ -30,7 +30,7 @@
 #include "siren_trunk_f16x3h.hip.h"
 #include "siren_trunk_f16x3w.hip.h"
 #include "siren_trunk_f32.hip.h"
-#include "siren_trunk_x1.hip.h"
+#include "siren_trunk_x1n.hip.h"
 #include "tiling.hip.h"
 
 namespace {
@@ -113,8 +113,9 @@ struct msiren_ctx {
     float mscale16[16] = {0};  // 16x16 kernel: factor of each layer's modulation row (the NEXT layer's weight scale, inverted)
     bool f16x3_ready = false;
     // single-product 16-bit trunk (MSIREN_PREC_BF16 / MSIREN_PREC_F16), H = 512
-    void *d_wpx1 = nullptr, *d_biasx1 = nullptr, *d_woutx1 = nullptr;
-    float *d_l0last = nullptr, *d_s0t512 = nullptr;
+    void *d_woutx1 = nullptr, *d_wpx1n = nullptr;  // last_layer.weight (fp16); weight stream of siren_trunk_x1n.hip.h
+    float* d_bias32x1 = nullptr;   // bias rows: fp32, in revolutions x the layer's weight scale
+    float* d_s0t512 = nullptr;
     float winvx1[64] = {0};
     bool x1_ready = false;
     int num_cus = 256;
@@ -393,11 +394,12 @@ int pack_trunk_x1(msiren_ctx* h) {
     const int H = h->H, L = h->L;
     const bool bf = h->cfg.precision == MSIREN_PREC_BF16;
     if (!(h->cfg.precision == MSIREN_PREC_BF16 || h->cfg.precision == MSIREN_PREC_F16)) return 0;
-    if (H != 512 || L < 2 || L > 65 || msiren::X1Lds<3>::total(L) > 160 * 1024)
+    if (H != 512 || L < 2 || L > 65 || msiren::X1nLds<3>::total(L) > 160 * 1024)
         return fail(MSIREN_E_INVALID, "precision bf16/f16 (single-product register-resident trunk) needs dim_hidden = 512 and 2 <= num_layers with its tables fitting the 160 KB LDS; got H=%d L=%d", H, L);
     const double two_pi = 6.283185307179586476925286766559;
-    const double c = (double)h->cfg.w0 / two_pi, c0 = (double)h->cfg.w0_initial / two_pi;
-    std::vector<uint16_t> wp((size_t)(L - 1) * 16 * 32 * 64 * 8), bias((size_t)(L - 1) * 512, 0), wout(512, 0);
+    const double c = (double)h->cfg.w0 / two_pi;
+    std::vector<uint16_t> wpn((size_t)(L - 1) * 16 * 16 * 2 * 64 * 8), wout(512, 0);  // chunk (l, t) = [16 k-steps][2 sub-tiles][64 lanes][8]
+    std::vector<float> bias32((size_t)(L - 1) * 512, 0.f);
     for (int l = 1; l < L; ++l) {
         const std::vector<float>& w = *get(h, "net.layers." + std::to_string(l) + ".weight");
         int e = 0;
@@ -408,32 +410,28 @@ int pack_trunk_x1(msiren_ctx* h) {
         }
         const double sc = std::ldexp(c, e);
         h->winvx1[l - 1] = (float)std::ldexp(1.0, -e);
+        // lane (r = lane & 15, q = lane >> 4), element j of k-step s of sub-tile u: output feature 32 t + 16 u + r, input
+        // feature 32 s + 16 (j >> 2) + 4 q + (j & 3) (the order of siren_trunk_f16x3n.hip.h)
         for (int t = 0; t < 16; ++t)
-            for (int s = 0; s < 32; ++s)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int f = 32 * t + (lane & 31);
-                        const int k = 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-                        const float ws = (float)((double)w[(size_t)f * H + k] * sc);
-                        wp[((((size_t)(l - 1) * 16 + t) * 32 + s) * 64 + lane) * 8 + j] = bf ? f32_to_bf16_rne(ws) : f32_to_f16_rne(ws);
-                    }
+            for (int s = 0; s < 16; ++s)
+                for (int u = 0; u < 2; ++u)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int f = 32 * t + 16 * u + (lane & 15);
+                            const int k = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+                            const float ws = (float)((double)w[(size_t)f * H + k] * sc);
+                            wpn[(((((size_t)(l - 1) * 16 + t) * 16 + s) * 2 + u) * 64 + lane) * 8 + j] = bf ? f32_to_bf16_rne(ws) : f32_to_f16_rne(ws);
+                        }
         if (const auto* b = h->cfg.use_bias ? get(h, "net.layers." + std::to_string(l) + ".bias") : nullptr)
-            for (int f = 0; f < H; ++f) bias[(size_t)(l - 1) * 512 + f] = f32_to_f16_rne((float)((double)(*b)[f] * c));
+            for (int f = 0; f < H; ++f) bias32[(size_t)(l - 1) * 512 + f] = (float)((double)(*b)[f] * sc);  // (x 2^e: the accumulator is scaled like the weights)
     }
     const auto* Wo = get(h, "net.last_layer.weight");
     for (int f = 0; f < H; ++f) wout[f] = f32_to_f16_rne((float)((double)(*Wo)[f] * c));
     const auto& W0 = *get(h, "net.layers.0.weight");
     const auto* B0 = h->cfg.use_bias ? get(h, "net.layers.0.bias") : nullptr;
-    std::vector<float> l0last(32 * 4, 0.f);
-    for (int i = 0; i < 32; ++i) {
-        const int f = 480 + i;
-        l0last[i * 4 + 0] = (float)((double)W0[(size_t)f * 2 + 0] * c0);
-        l0last[i * 4 + 1] = (float)((double)W0[(size_t)f * 2 + 1] * c0);
-        l0last[i * 4 + 2] = B0 ? (float)((double)(*B0)[f] * c0) : 0.f;
-    }
     const std::vector<float>* g = &h->grid_host;  // pack_trunk ran first
     if (g->size() != (size_t)h->P * 2) return fail(MSIREN_E_STATE, "grid buffer missing");
-    std::vector<float> tab((size_t)128 * h->P * 4);
+    std::vector<float> tab((size_t)128 * h->P * 4);  // layer-0 activation table S0T[f/4][p][f%4] = act0(w0_initial * (W0 x_p + b0))
     const bool morlet = h->cfg.activation == MSIREN_ACT_MORLET;
     for (int f = 0; f < 512; ++f)
         for (int pidx = 0; pidx < h->P; ++pidx) {
@@ -451,8 +449,8 @@ int pack_trunk_x1(msiren_ctx* h) {
         return 0;
     };
     int rc;
-    if ((rc = up16(&h->d_wpx1, wp)) || (rc = up16(&h->d_biasx1, bias)) || (rc = up16(&h->d_woutx1, wout))) return rc;
-    if ((rc = upload(&h->d_l0last, l0last)) || (rc = upload(&h->d_s0t512, tab))) return rc;
+    if ((rc = up16(&h->d_wpx1n, wpn)) || (rc = up16(&h->d_woutx1, wout))) return rc;
+    if ((rc = upload(&h->d_bias32x1, bias32)) || (rc = upload(&h->d_s0t512, tab))) return rc;
     h->x1_ready = true;
     return 0;
 }
@@ -815,11 +813,9 @@ int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int gr
 
 int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     msiren::TrunkX1Params p{};
-    p.grid = h->d_grid;
-    p.l0last = h->d_l0last;
     p.s0t = h->d_s0t512;
-    p.wp = (const unsigned short*)h->d_wpx1;
-    p.bias = (const _Float16*)h->d_biasx1;
+    p.wp = (const unsigned short*)h->d_wpx1n;
+    p.bias32 = h->d_bias32x1;
     p.wout = (const _Float16*)h->d_woutx1;
     p.mods = mods_dev;
     p.out = out_dev;
@@ -842,26 +838,26 @@ int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_
 }
 
 int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int grid) {
-    const int lds = msiren::X1Lds<3>::total(h->L);
     const bool bf = h->cfg.precision == MSIREN_PREC_BF16, mor = h->cfg.activation == MSIREN_ACT_MORLET, res = h->cfg.residual != 0;
-#define MSIREN_X1_LAUNCH(BF, A, RS)                                                                  \
+    const int lds = msiren::X1nLds<3>::total(h->L);
+#define MSIREN_X1N_LAUNCH(BF, A, RS)                                                                 \
     do {                                                                                             \
-        auto k = msiren::siren_trunk_x1_kernel<BF, A, RS, 3>;                                        \
+        auto k = msiren::siren_trunk_x1n_kernel<BF, A, RS, 3>;                                       \
         if (h->lds_attr_x1 < lds) { /* one instance per handle (precision, activation, residual are the handle's) */ \
             HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
             h->lds_attr_x1 = lds;                                                                    \
         }                                                                                            \
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);                       \
-        std::snprintf(h->last_trunk, sizeof h->last_trunk, "siren_trunk_x1_kernel<%d,%d,%d,3>", BF, A, RS); \
+        std::snprintf(h->last_trunk, sizeof h->last_trunk, "siren_trunk_x1n_kernel<%d,%d,%d,3>", BF, A, RS); \
     } while (0)
     if (bf) {
-        if (mor) { if (res) MSIREN_X1_LAUNCH(1, 1, 1); else MSIREN_X1_LAUNCH(1, 1, 0); }
-        else     { if (res) MSIREN_X1_LAUNCH(1, 0, 1); else MSIREN_X1_LAUNCH(1, 0, 0); }
+        if (mor) { if (res) MSIREN_X1N_LAUNCH(1, 1, 1); else MSIREN_X1N_LAUNCH(1, 1, 0); }
+        else     { if (res) MSIREN_X1N_LAUNCH(1, 0, 1); else MSIREN_X1N_LAUNCH(1, 0, 0); }
     } else {
-        if (mor) { if (res) MSIREN_X1_LAUNCH(0, 1, 1); else MSIREN_X1_LAUNCH(0, 1, 0); }
-        else     { if (res) MSIREN_X1_LAUNCH(0, 0, 1); else MSIREN_X1_LAUNCH(0, 0, 0); }
+        if (mor) { if (res) MSIREN_X1N_LAUNCH(0, 1, 1); else MSIREN_X1N_LAUNCH(0, 1, 0); }
+        else     { if (res) MSIREN_X1N_LAUNCH(0, 0, 1); else MSIREN_X1N_LAUNCH(0, 0, 0); }
     }
-#undef MSIREN_X1_LAUNCH
+#undef MSIREN_X1N_LAUNCH
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -919,7 +915,7 @@ int launch_trunk_f32_cond(msiren_ctx* h, const float* mods_dev, int64_t B, float
     p.cond_val = h->range_epoch;
     p.items = (int)(B * cpp);
     p.host_flag = h->status_dev;
-    const int grid = (int)std::min<int64_t>(p.items, 2 * (int64_t)h->num_cus);
+    const int grid = (int)std::min<int64_t>(p.items, (int64_t)h->num_cus);
     if (h->cfg.activation == MSIREN_ACT_MORLET)
         hipLaunchKernelGGL(msiren::siren_trunk_f32_cond_kernel<1>, dim3(grid), dim3(256), 0, c.s, p);
     else
@@ -1391,9 +1387,9 @@ int msiren_destroy(msiren_handle h) {
     if (h->status_host) (void)hipHostFree((void*)h->status_host);
     if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
     if (h->d_wp16n) (void)hipFree(h->d_wp16n);
-    for (void* q : {h->d_wpx1, h->d_biasx1, h->d_woutx1})
+    for (void* q : {h->d_woutx1, h->d_wpx1n, (void*)h->d_bias32x1})
         if (q) (void)hipFree(q);
-    float* ptrs[] = {h->d_dump, h->d_l0last, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
+    float* ptrs[] = {h->d_dump, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     DevBuf* bufs[] = {&h->sc[0].mods2, &h->sc[1].mods2, &h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,

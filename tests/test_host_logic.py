@@ -137,6 +137,21 @@ def test_committed_bench_line_follows_the_contract():
     assert c["kind"] == "port" and c["unit"] == line["unit"] and c["cores"] >= 1
     e = line["extra"]
     assert 0 < e["host_to_host_mpixel_s"] < line["value"] and e["reconstruct_mpixel_s"] > 0
+    # round 4's line (profiles/r4/10_final/bench_driver_like.json): the roofline block names the kernel of the TIMED region as the
+    # library reports it, is consistent with `value`, says where its traffic figure comes from; every other BASELINE
+    # configuration rides along
+    l4 = json.loads(open(os.path.join(root, "profiles", "r4", "10_final", "bench_driver_like.json")).read().strip().splitlines()[-1])
+    r4 = l4["roofline"]
+    assert r4["kernel"] == "siren_trunk_f16x3n_kernel<0,3,5>" and r4["timed_region_kernels"][0]["kernel"] == r4["kernel"]
+    assert abs(r4["avg_launch_ms"] - l4["ms_per_step"]) < 0.02 * l4["ms_per_step"] and r4["flops_per_launch"] == 525824 * 576 * 400
+    assert abs(r4["achieved"] - r4["flops_per_launch"] / (r4["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r4["achieved"]
+    assert abs(r4["frac"] - r4["achieved"] / r4["peak"]) < 1e-9 and "profiles/r4/" in r4["traffic_source"] and r4["traffic"] > 0
+    assert l4["roofline_kernel_alone"]["kernel"] == "siren_trunk_f16x3w_kernel<0,4>"
+    assert l4["config"]["ranks"][0]["pci_bus_id"] and l4["cpu_baseline"]["kind"] == "port"
+    for name in ("config3_64_slices_n1", "config3_64_slices_n1_one_stream", "config3_8_slices_per_rank", "config4_morlet", "fp32_trunk",
+                 "config5_deep_residual_bf16"):
+        c = l4["extra"]["configs"][name]
+        assert c["value"] > 0 and 0.1 < c["kernel_alone_frac"] < 1.0 and c["kernel"].startswith("siren_trunk_"), (name, c)
     # the strong-scaling form of BASELINE configs[2] on one GPU, and its 4-rank rehearsal on one card
     for name, n in (("bench_strong64_n1.json", 1), ("bench_strong64_gloo4_one_card.json", 4)):
         s = json.loads(open(os.path.join(root, "profiles", "r2", "10_final", name)).read().strip().splitlines()[-1])
