@@ -114,6 +114,7 @@ struct msiren_ctx {
     bool f16x3_ready = false;
     // single-product 16-bit trunk (MSIREN_PREC_BF16 / MSIREN_PREC_F16), H = 512
     void *d_woutx1 = nullptr, *d_wpx1n = nullptr;  // last_layer.weight (fp16); weight stream of siren_trunk_x1n.hip.h
+
     float* d_bias32x1 = nullptr;   // bias rows: fp32, in revolutions x the layer's weight scale
     float* d_s0t512 = nullptr;
     float winvx1[64] = {0};
