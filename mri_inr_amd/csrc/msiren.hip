@@ -31,6 +31,7 @@
 #include "siren_trunk_f16x3w.hip.h"
 #include "siren_trunk_f32.hip.h"
 #include "siren_trunk_x1n.hip.h"
+#include "siren_trunk_x1w.hip.h"
 #include "tiling.hip.h"
 
 namespace {
@@ -114,6 +115,9 @@ struct msiren_ctx {
     bool f16x3_ready = false;
     // single-product 16-bit trunk (MSIREN_PREC_BF16 / MSIREN_PREC_F16), H = 512
     void *d_woutx1 = nullptr, *d_wpx1n = nullptr;  // last_layer.weight (fp16); weight stream of siren_trunk_x1n.hip.h
+    void* d_wpx1w = nullptr;       // weight stream of siren_trunk_x1w.hip.h (weight-stationary: 64 KB per layer, N-pass and wave)
+    int x1_ws = 1;                 // MSIREN_X1_WS=0: the register-resident kernel (A/B knob, read at create)
+    int lds_attr_x1w = 0;
 
     float* d_bias32x1 = nullptr;   // bias rows: fp32, in revolutions x the layer's weight scale
     float* d_s0t512 = nullptr;
@@ -395,12 +399,13 @@ int pack_trunk_x1(msiren_ctx* h) {
     const int H = h->H, L = h->L;
     const bool bf = h->cfg.precision == MSIREN_PREC_BF16;
     if (!(h->cfg.precision == MSIREN_PREC_BF16 || h->cfg.precision == MSIREN_PREC_F16)) return 0;
-    if (H != 512 || L < 2 || L > 65 || msiren::X1nLds<3>::total(L) > 160 * 1024)
+    if (H != 512 || L < 2 || L > 65 || msiren::X1nLds<3>::total(L) > 160 * 1024 || msiren::X1wLds::total(L) > 160 * 1024)
         return fail(MSIREN_E_INVALID, "precision bf16/f16 (single-product register-resident trunk) needs dim_hidden = 512 and 2 <= num_layers with its tables fitting the 160 KB LDS; got H=%d L=%d", H, L);
     const double two_pi = 6.283185307179586476925286766559;
     const double c = (double)h->cfg.w0 / two_pi;
     std::vector<uint16_t> wpn((size_t)(L - 1) * 16 * 16 * 2 * 64 * 8), wout(512, 0);  // chunk (l, t) = [16 k-steps][2 sub-tiles][64 lanes][8]
     std::vector<float> bias32((size_t)(L - 1) * 512, 0.f);
+    std::vector<uint16_t> wpw(wpn.size());
     for (int l = 1; l < L; ++l) {
         const std::vector<float>& w = *get(h, "net.layers." + std::to_string(l) + ".weight");
         int e = 0;
@@ -423,6 +428,19 @@ int pack_trunk_x1(msiren_ctx* h) {
                             const float ws = (float)((double)w[(size_t)f * H + k] * sc);
                             wpn[(((((size_t)(l - 1) * 16 + t) * 16 + s) * 2 + u) * 64 + lane) * 8 + j] = bf ? f32_to_bf16_rne(ws) : f32_to_f16_rne(ws);
                         }
+        // weight-stationary kernel: block ((l - 1) * 2 + n) * 4 + wave = [16 k-steps][4 tiles][64 lanes][8]: output feature
+        // 256 n + 64 wave + 16 t + r, input feature as above
+        for (int n = 0; n < 2; ++n)
+            for (int wv = 0; wv < 4; ++wv)
+                for (int s = 0; s < 16; ++s)
+                    for (int t = 0; t < 4; ++t)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int f = 256 * n + 64 * wv + 16 * t + (lane & 15);
+                                const int k = 32 * s + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+                                const float ws = (float)((double)w[(size_t)f * H + k] * sc);
+                                wpw[((((((size_t)(l - 1) * 2 + n) * 4 + wv) * 16 + s) * 4 + t) * 64 + lane) * 8 + j] = bf ? f32_to_bf16_rne(ws) : f32_to_f16_rne(ws);
+                            }
         if (const auto* b = h->cfg.use_bias ? get(h, "net.layers." + std::to_string(l) + ".bias") : nullptr)
             for (int f = 0; f < H; ++f) bias32[(size_t)(l - 1) * 512 + f] = (float)((double)(*b)[f] * sc);  // (x 2^e: the accumulator is scaled like the weights)
     }
@@ -450,7 +468,7 @@ int pack_trunk_x1(msiren_ctx* h) {
         return 0;
     };
     int rc;
-    if ((rc = up16(&h->d_wpx1n, wpn)) || (rc = up16(&h->d_woutx1, wout))) return rc;
+    if ((rc = up16(&h->d_wpx1n, wpn)) || (rc = up16(&h->d_wpx1w, wpw)) || (rc = up16(&h->d_woutx1, wout))) return rc;
     if ((rc = upload(&h->d_bias32x1, bias32)) || (rc = upload(&h->d_s0t512, tab))) return rc;
     h->x1_ready = true;
     return 0;
@@ -838,8 +856,33 @@ int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_
     return queue_launched(h, launch_trunk_x1_kernel(h, p, grid));
 }
 
-int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p, int grid) {
+int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p0, int grid) {
     const bool bf = h->cfg.precision == MSIREN_PREC_BF16, mor = h->cfg.activation == MSIREN_ACT_MORLET, res = h->cfg.residual != 0;
+    msiren::TrunkX1Params p = p0;
+    if (h->x1_ws && h->L >= 3) {  // weight-stationary (siren_trunk_x1w.hip.h; its layer pipeline needs a hidden layer before the final one)
+        p.wp = (const unsigned short*)h->d_wpx1w;
+        const int lds = msiren::X1wLds::total(h->L);
+#define MSIREN_X1W_LAUNCH(BF, A, RS)                                                                 \
+    do {                                                                                             \
+        auto k = msiren::siren_trunk_x1w_kernel<BF, A, RS>;                                          \
+        if (h->lds_attr_x1w < lds) {                                                                 \
+            HIPCHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            h->lds_attr_x1w = lds;                                                                   \
+        }                                                                                            \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->sc[h->cur].s, p);                       \
+        std::snprintf(h->last_trunk, sizeof h->last_trunk, "siren_trunk_x1w_kernel<%d,%d,%d>", BF, A, RS); \
+    } while (0)
+        if (bf) {
+            if (mor) { if (res) MSIREN_X1W_LAUNCH(1, 1, 1); else MSIREN_X1W_LAUNCH(1, 1, 0); }
+            else     { if (res) MSIREN_X1W_LAUNCH(1, 0, 1); else MSIREN_X1W_LAUNCH(1, 0, 0); }
+        } else {
+            if (mor) { if (res) MSIREN_X1W_LAUNCH(0, 1, 1); else MSIREN_X1W_LAUNCH(0, 1, 0); }
+            else     { if (res) MSIREN_X1W_LAUNCH(0, 0, 1); else MSIREN_X1W_LAUNCH(0, 0, 0); }
+        }
+#undef MSIREN_X1W_LAUNCH
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     const int lds = msiren::X1nLds<3>::total(h->L);
 #define MSIREN_X1N_LAUNCH(BF, A, RS)                                                                 \
     do {                                                                                             \
@@ -1353,6 +1396,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_HOST_CHUNKS")) h->host_chunks = std::max(1, std::min(std::atoi(e), 16));
     if (const char* e = std::getenv("MSIREN_QUEUE_START")) h->queue_start = (unsigned)std::strtoul(e, nullptr, 0);
     if (const char* e = std::getenv("MSIREN_F16_WS")) h->f16_ws = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_X1_WS")) h->x1_ws = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_RANGE_RERUN")) h->cond_rerun = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_SPLIT_MIN")) h->split_min = std::max<long long>(0, std::atoll(e));
     if (const char* e = std::getenv("MSIREN_LINEAR_TILE_MIN")) h->lin_tile_min = std::max(0, std::atoi(e));
@@ -1388,7 +1432,7 @@ int msiren_destroy(msiren_handle h) {
     if (h->status_host) (void)hipHostFree((void*)h->status_host);
     if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
     if (h->d_wp16n) (void)hipFree(h->d_wp16n);
-    for (void* q : {h->d_woutx1, h->d_wpx1n, (void*)h->d_bias32x1})
+    for (void* q : {h->d_woutx1, h->d_wpx1n, h->d_wpx1w, (void*)h->d_bias32x1})
         if (q) (void)hipFree(q);
     float* ptrs[] = {h->d_dump, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
     for (float* p : ptrs)

@@ -304,7 +304,7 @@ def test_bench_single_gpu_line_carries_roofline_cpu_baseline_and_extras():
     cfgs = ex["configs"]
     want = {"config3_64_slices_n1": "siren_trunk_f16x3w_kernel<0,4>", "config3_64_slices_n1_one_stream": "siren_trunk_f16x3w_kernel<0,4>",
             "config3_8_slices_per_rank": "siren_trunk_f16x3w_kernel<0,4>", "config4_morlet": "siren_trunk_f16x3w_kernel<1,4>",
-            "fp32_trunk": "siren_trunk_f32_kernel<256,0,0>", "config5_deep_residual_bf16": "siren_trunk_x1n_kernel<1,0,1,3>"}
+            "fp32_trunk": "siren_trunk_f32_kernel<256,0,0>", "config5_deep_residual_bf16": "siren_trunk_x1w_kernel<1,0,1>"}
     for name, kern in want.items():
         c = cfgs[name]
         assert "error" not in c, (name, c)

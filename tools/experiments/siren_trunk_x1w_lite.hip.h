@@ -1,4 +1,4 @@
-// RECORD ONLY -- not part of the product build (profiles/r4/05_config5_x1w_lite_vs_x1n_ab.txt: correct, 8-13 % slower than the
+// RECORD ONLY -- not part of the product build (profiles/r4/05_config5_weight_stationary_ab.txt: correct, 8-13 % slower than the
 // register-resident kernel because its epilogue is not overlapped with MFMAs; the starting point for an overlapped version).
 // It built against mri_inr_amd/csrc at the commit that added this file: msiren.hip packed its weight stream as
 // block ((l - 1) * 2 + n) * 4 + wave = [16 k-steps][4 tiles][64 lanes][8] (output feature 256 n + 64 wave + 16 t + (lane & 15),
