@@ -850,8 +850,12 @@ int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_
     if (units > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     p.total_units = (int)units;
     p.plan = h->plan;
+    const bool ws = h->x1_ws && h->L >= 3;
     const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
-    int rc = queue_for_launch(h, (units + 3) / 4, &p.pass_counter, &p.pass_base);
+    // (the weight-stationary kernel lays its passes out itself: x1w_schedule, 4-unit passes and a last round of 2-unit ones)
+    msiren::X1wSchedule sch = msiren::x1w_schedule(units, grid);
+    const int64_t npasses = ws ? (int64_t)sch.n4 + sch.n2 : (units + 3) / 4;
+    int rc = queue_for_launch(h, npasses, &p.pass_counter, &p.pass_base);
     if (rc) return rc;
     return queue_launched(h, launch_trunk_x1_kernel(h, p, grid));
 }

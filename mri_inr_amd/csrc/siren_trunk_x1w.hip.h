@@ -40,6 +40,20 @@ struct X1wLds {  // byte offsets into dynamic LDS
     static __host__ __device__ constexpr int total(int L) { return winv(L) + 256; }
 };
 
+struct X1wSchedule {
+    int n4, n2;
+};
+__host__ __device__ inline X1wSchedule x1w_schedule(long long units, int grid) {
+    X1wSchedule s{0, 0};
+    if (units <= 0 || grid <= 0) return s;
+    const long long full = units / (4LL * grid);
+    s.n4 = (int)(full * grid);
+    const long long rem = units - 4LL * s.n4;  // < 4 * grid
+    if (rem <= 2LL * grid) s.n2 = (int)((rem + 1) / 2);
+    else s.n4 += (int)((rem + 3) / 4);
+    return s;
+}
+
 template <int BF, int ACT, int RES>
 __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p) {
     using LY = X1wLds;
@@ -53,7 +67,10 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
     const int P = p.P;
 
     const int total_units = __builtin_amdgcn_readfirstlane(p.plan ? p.plan[1] : p.total_units);
-    const unsigned npasses = (unsigned)(total_units + 3) >> 2;
+    // passes [0, n4) take 4 units, [n4, n4 + n2) take 2 (x1w_schedule: whole rounds of 4-unit passes; what is left, if it is at
+    // most two units per workgroup, as one round of 2-unit passes -- half a round instead of a whole one at a launch's end)
+    const X1wSchedule sch = x1w_schedule(total_units, (int)gridDim.x);
+    const unsigned npasses = (unsigned)(sch.n4 + sch.n2);
     int cur_pass = (int)blockIdx.x;
     if ((unsigned)cur_pass >= npasses) return;
 
@@ -81,8 +98,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
         return reinterpret_cast<const unsigned char*>(p.wp) + ((size_t)((l - 1) * 2 + n) * 4 + wave) * 65536;
     };
 #define MSIREN_X1W_A(S, T) (16 * (S) + 4 * (T))
+// (s_nop 4: a VALU-written SGPR -- a pointer the compiler spilled and restores with v_readlane_b32 -- may be read by a vector
+// memory instruction only 5 wait states later, and the compiler does not pad in front of an asm statement.  The fp16 instances
+// spill pointers the bf16 ones keep; without the pad their first load after such a restore went to a stale address and the
+// launch died with an aperture violation -- found with rocgdb's precise-memory mode, kept out by tests/test_asm_hazards.py.)
 #define MSIREN_X1W_LOADK(S, WB)                                                                                        \
-    asm volatile("global_load_dwordx4 a[%2:%3], %0, %1 offset:0\n\t"                                                   \
+    asm volatile("s_nop 4\n\t"                                                                                         \
+                 "global_load_dwordx4 a[%2:%3], %0, %1 offset:0\n\t"                                                   \
                  "global_load_dwordx4 a[%4:%5], %0, %1 offset:1024\n\t"                                                \
                  "global_load_dwordx4 a[%6:%7], %0, %1 offset:2048\n\t"                                                \
                  "global_load_dwordx4 a[%8:%9], %0, %1 offset:3072"                                                    \
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
         if ((GAPS) && !(MSIREN_X1W_ABL & 1)) MSIREN_X1W_STEP(8 * (S) + (I), NP, UP, LASTP);                            \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     } while (0)
-#define MSIREN_X1W_KSTEP(N, U, S, NP, UP, LASTP, GAPS)                                                                       \
+#define MSIREN_X1W_KSTEP(N, U, S, NP, UP, LASTP, GAPS, NB)                                                                       \
     do {                                                                                                               \
         MSIREN_X1W_HOLD();                                                                                             \
         if ((U) == 0) MSIREN_X1W_WAITK(S);                                                                             \
@@ -254,13 +276,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
         MSIREN_X1W_M(S, 1, 0, 2, N, U, NP, UP, LASTP, GAPS); MSIREN_X1W_M(S, 1, 1, 3, N, U, NP, UP, LASTP, GAPS);                  \
         MSIREN_X1W_M(S, 2, 0, 4, N, U, NP, UP, LASTP, GAPS); MSIREN_X1W_M(S, 2, 1, 5, N, U, NP, UP, LASTP, GAPS);                  \
         MSIREN_X1W_M(S, 3, 0, 6, N, U, NP, UP, LASTP, GAPS); MSIREN_X1W_M(S, 3, 1, 7, N, U, NP, UP, LASTP, GAPS);                  \
-        if ((U) == 3) MSIREN_X1W_LOADK(S, wnext_);                                                                     \
+        if ((U) == (NB) - 1) MSIREN_X1W_LOADK(S, wnext_);                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     } while (0)
 
 // LAST (compile-time): the final hidden layer -- its outputs only meet last_layer.weight (a dot product per coordinate), no
 // image is written.  LASTP: the same for the slot before.  lp_: that slot's layer (l, or l - 1 for a layer's first slot).
-#define MSIREN_X1W_SLOT(N, U, LAST, NP, UP, LASTP, GAPS, BAR)                                                                     \
+#define MSIREN_X1W_SLOT(N, U, LAST, NP, UP, LASTP, GAPS, BAR, NB)                                                                     \
     do {                                                                                                               \
         /* (opaque: as constants the units' offsets are folded into dozens of loop-invariant address registers) */     \
         unsigned uoff_ = (U) * 32768u, poff_ = (UP) * 32768u;                                                          \
@@ -272,7 +294,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
         const unsigned char* const pmr_ = modsL + ((lp_ & 1) * 4 + (UP)) * 1024 + (NP) * 512;                          \
         [[maybe_unused]] const float pwi_ = winvT[lp_ > 0 ? lp_ - 1 : 0];                                              \
         /* what the unit's last slot fetches: (l, 1) behind (l, 0); (l + 1, 0) behind (l, 1); layer 1 of the next pass at the end */ \
-        const unsigned char* const wnext_ = (N) == 0 ? wblock(l, 1) : wblock((LAST) ? 1 : l + 1, 0);                   \
+        const unsigned char* wnext_ = (N) == 0 ? wblock(l, 1) : wblock((LAST) ? 1 : l + 1, 0);                         \
+        asm volatile("" : "+s"(wnext_)); /* (opaque: the 16 k-step pointers of layer 1 are not kept in 32 SGPRs for the whole kernel) */ \
         if (BAR) {                                                                                                     \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
             if (!(MSIREN_X1W_ABL & 2)) __builtin_amdgcn_s_barrier(); /* every wave is past the MFMAs of the slot before: its image may be updated in \
@@ -290,14 +313,14 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
                      "+v"(accS[(U) & 1][2][0]), "+v"(accS[(U) & 1][2][1]), "+v"(accS[(U) & 1][3][0]), "+v"(accS[(U) & 1][3][1])); \
         if (GAPS) MSIREN_X1W_EPI_BEGIN(NP, UP, LASTP);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        MSIREN_X1W_KSTEP(N, U, 0, NP, UP, LASTP, GAPS); MSIREN_X1W_KSTEP(N, U, 1, NP, UP, LASTP, GAPS);                            \
-        MSIREN_X1W_KSTEP(N, U, 2, NP, UP, LASTP, GAPS); MSIREN_X1W_KSTEP(N, U, 3, NP, UP, LASTP, GAPS);                            \
-        MSIREN_X1W_KSTEP(N, U, 4, NP, UP, LASTP, GAPS); MSIREN_X1W_KSTEP(N, U, 5, NP, UP, LASTP, GAPS);                            \
-        MSIREN_X1W_KSTEP(N, U, 6, NP, UP, LASTP, GAPS); MSIREN_X1W_KSTEP(N, U, 7, NP, UP, LASTP, GAPS);                            \
-        MSIREN_X1W_KSTEP(N, U, 8, NP, UP, LASTP, GAPS); MSIREN_X1W_KSTEP(N, U, 9, NP, UP, LASTP, GAPS);                            \
-        MSIREN_X1W_KSTEP(N, U, 10, NP, UP, LASTP, GAPS); MSIREN_X1W_KSTEP(N, U, 11, NP, UP, LASTP, GAPS);                          \
-        MSIREN_X1W_KSTEP(N, U, 12, NP, UP, LASTP, GAPS); MSIREN_X1W_KSTEP(N, U, 13, NP, UP, LASTP, GAPS);                          \
-        MSIREN_X1W_KSTEP(N, U, 14, NP, UP, LASTP, GAPS); MSIREN_X1W_KSTEP(N, U, 15, NP, UP, LASTP, GAPS);                          \
+        MSIREN_X1W_KSTEP(N, U, 0, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 1, NP, UP, LASTP, GAPS, NB);                            \
+        MSIREN_X1W_KSTEP(N, U, 2, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 3, NP, UP, LASTP, GAPS, NB);                            \
+        MSIREN_X1W_KSTEP(N, U, 4, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 5, NP, UP, LASTP, GAPS, NB);                            \
+        MSIREN_X1W_KSTEP(N, U, 6, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 7, NP, UP, LASTP, GAPS, NB);                            \
+        MSIREN_X1W_KSTEP(N, U, 8, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 9, NP, UP, LASTP, GAPS, NB);                            \
+        MSIREN_X1W_KSTEP(N, U, 10, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 11, NP, UP, LASTP, GAPS, NB);                          \
+        MSIREN_X1W_KSTEP(N, U, 12, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 13, NP, UP, LASTP, GAPS, NB);                          \
+        MSIREN_X1W_KSTEP(N, U, 14, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 15, NP, UP, LASTP, GAPS, NB);                          \
         if (GAPS) MSIREN_X1W_EPI_END(NP, UP, LASTP);                                                                   \
     } while (0)
 // A final-layer slot's own epilogue, BEHIND its MFMAs and on the accumulator set it has just filled: sine, residual, modulation
@@ -332,38 +355,58 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
 // barriers of (a) lie in between for U = 0..2, and the one at (0,1) covers U = 3.  Slots (0,2), (0,3), (1,0) need none.
 #define MSIREN_X1W_LAYER()                                                                                             \
     do {                                                                                                               \
-        MSIREN_X1W_SLOT(0, 0, false, 1, 3, false, true, true);                                                         \
-        MSIREN_X1W_SLOT(0, 1, false, 0, 0, false, true, true);                                                         \
+        MSIREN_X1W_SLOT(0, 0, false, 1, 3, false, true, true, 4);                                                         \
+        MSIREN_X1W_SLOT(0, 1, false, 0, 0, false, true, true, 4);                                                         \
         stage_mods(l + 1); /* (no asm load is in flight here: the compiler's own wait drains nothing of ours) */       \
-        MSIREN_X1W_SLOT(0, 2, false, 0, 1, false, true, false);                                                        \
-        MSIREN_X1W_SLOT(0, 3, false, 0, 2, false, true, false);                                                        \
-        MSIREN_X1W_SLOT(1, 0, false, 0, 3, false, true, false);                                                        \
-        MSIREN_X1W_SLOT(1, 1, false, 1, 0, false, true, true);                                                         \
-        MSIREN_X1W_SLOT(1, 2, false, 1, 1, false, true, true);                                                         \
-        MSIREN_X1W_SLOT(1, 3, false, 1, 2, false, true, true);                                                         \
+        MSIREN_X1W_SLOT(0, 2, false, 0, 1, false, true, false, 4);                                                        \
+        MSIREN_X1W_SLOT(0, 3, false, 0, 2, false, true, false, 4);                                                        \
+        MSIREN_X1W_SLOT(1, 0, false, 0, 3, false, true, false, 4);                                                        \
+        MSIREN_X1W_SLOT(1, 1, false, 1, 0, false, true, true, 4);                                                         \
+        MSIREN_X1W_SLOT(1, 2, false, 1, 1, false, true, true, 4);                                                         \
+        MSIREN_X1W_SLOT(1, 3, false, 1, 2, false, true, true, 4);                                                         \
     } while (0)
 // the final hidden layer: its first slot still carries the layer before's last epilogue in its gaps; nothing is stored
 // into an image any more (barriers: the two that order the last in-place stores against their readers)
 #define MSIREN_X1W_FINAL_LAYER()                                                                                       \
     do {                                                                                                               \
-        MSIREN_X1W_SLOT(0, 0, true, 1, 3, false, true, true);    MSIREN_X1W_FINAL_EPI(0, 0);                           \
-        MSIREN_X1W_SLOT(0, 1, true, 0, 0, true, false, true);    MSIREN_X1W_FINAL_EPI(0, 1);                           \
-        MSIREN_X1W_SLOT(0, 2, true, 0, 1, true, false, false);   MSIREN_X1W_FINAL_EPI(0, 2);                           \
-        MSIREN_X1W_SLOT(0, 3, true, 0, 2, true, false, false);   MSIREN_X1W_FINAL_EPI(0, 3);                           \
-        MSIREN_X1W_SLOT(1, 0, true, 0, 3, true, false, false);   MSIREN_X1W_FINAL_EPI(1, 0);                           \
-        MSIREN_X1W_SLOT(1, 1, true, 1, 0, true, false, false);   MSIREN_X1W_FINAL_EPI(1, 1);                           \
-        MSIREN_X1W_SLOT(1, 2, true, 1, 1, true, false, false);   MSIREN_X1W_FINAL_EPI(1, 2);                           \
-        MSIREN_X1W_SLOT(1, 3, true, 1, 2, true, false, false);   MSIREN_X1W_FINAL_EPI(1, 3);                           \
+        MSIREN_X1W_SLOT(0, 0, true, 1, 3, false, true, true, 4);    MSIREN_X1W_FINAL_EPI(0, 0);                           \
+        MSIREN_X1W_SLOT(0, 1, true, 0, 0, true, false, true, 4);    MSIREN_X1W_FINAL_EPI(0, 1);                           \
+        MSIREN_X1W_SLOT(0, 2, true, 0, 1, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(0, 2);                           \
+        MSIREN_X1W_SLOT(0, 3, true, 0, 2, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(0, 3);                           \
+        MSIREN_X1W_SLOT(1, 0, true, 0, 3, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(1, 0);                           \
+        MSIREN_X1W_SLOT(1, 1, true, 1, 0, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(1, 1);                           \
+        MSIREN_X1W_SLOT(1, 2, true, 1, 1, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(1, 2);                           \
+        MSIREN_X1W_SLOT(1, 3, true, 1, 2, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(1, 3);                           \
+    } while (0)
+
+// The same for a pass of TWO units (slots (0,0) (0,1) (1,0) (1,1); the second unit's slots fetch).  Barriers: (a) (0,0) [carries
+// (l-1, 1, 1)] and (1,1) [carries (1,0)]; (b) unit 1's image is stored into during (0,0) of the next layer and read in (0,1).
+#define MSIREN_X1W_LAYER2()                                                                                            \
+    do {                                                                                                               \
+        MSIREN_X1W_SLOT(0, 0, false, 1, 1, false, true, true, 2);                                                      \
+        MSIREN_X1W_SLOT(0, 1, false, 0, 0, false, true, true, 2);                                                      \
+        MSIREN_X1W_SLOT(1, 0, false, 0, 1, false, true, false, 2);                                                     \
+        stage_mods(l + 1); /* (behind a slot that has waited for every weight load: none of ours is in flight) */      \
+        MSIREN_X1W_SLOT(1, 1, false, 1, 0, false, true, true, 2);                                                      \
+    } while (0)
+#define MSIREN_X1W_FINAL_LAYER2()                                                                                      \
+    do {                                                                                                               \
+        MSIREN_X1W_SLOT(0, 0, true, 1, 1, false, true, true, 2);    MSIREN_X1W_FINAL_EPI(0, 0);                        \
+        MSIREN_X1W_SLOT(0, 1, true, 0, 0, true, false, true, 2);    MSIREN_X1W_FINAL_EPI(0, 1);                        \
+        MSIREN_X1W_SLOT(1, 0, true, 0, 1, true, false, false, 2);   MSIREN_X1W_FINAL_EPI(1, 0);                        \
+        MSIREN_X1W_SLOT(1, 1, true, 1, 0, true, false, false, 2);   MSIREN_X1W_FINAL_EPI(1, 1);                        \
     } while (0)
 
     for (int pass = 0; (unsigned)cur_pass < npasses; ++pass) {
         // ---- the pass's four units (clamped into the batch; surplus units are computed and not stored) ----
+        const int nb = cur_pass < sch.n4 ? 4 : 2;
+        const int u0 = cur_pass < sch.n4 ? 4 * cur_pass : 4 * sch.n4 + 2 * (cur_pass - sch.n4);
         int patch[4], c0[4];
         bool live[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            int unit = cur_pass * 4 + u;
-            live[u] = unit < total_units;
+            int unit = u0 + (u < nb ? u : 0);
+            live[u] = u < nb && unit < total_units;
             unit = live[u] ? unit : total_units - 1;
             patch[u] = unit / p.units_per_patch;
             c0[u] = (unit - patch[u] * p.units_per_patch) * 32;
@@ -433,8 +476,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
 
         // ---- hidden layers ----
         int l = 1;
-        for (; l < L - 1; ++l) MSIREN_X1W_LAYER();
-        MSIREN_X1W_FINAL_LAYER();  // l == L - 1
+        if (nb == 4) {
+            for (; l < L - 1; ++l) MSIREN_X1W_LAYER();
+            MSIREN_X1W_FINAL_LAYER();  // l == L - 1
+        } else {
+            for (; l < L - 1; ++l) MSIREN_X1W_LAYER2();
+            MSIREN_X1W_FINAL_LAYER2();
+        }
 
         // ---- last_layer: sum over the lane's feature sub-groups, over the waves through LDS, sine, store ----
 #pragma unroll
@@ -459,6 +507,8 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
     MSIREN_X1W_HOLD();
 #undef MSIREN_X1W_HOLD
 #undef MSIREN_X1W_LAYER
+#undef MSIREN_X1W_LAYER2
+#undef MSIREN_X1W_FINAL_LAYER2
 #undef MSIREN_X1W_FINAL_LAYER
 #undef MSIREN_X1W_FINAL_EPI
 #undef MSIREN_X1W_F16

@@ -199,3 +199,95 @@ def test_no_load_destination_is_touched_while_the_load_is_in_flight(trunk_isa, t
         text = _compile(tmp_path, ws, f"abl{abl}", extra=(f"-DMSIREN_WS_ABL={abl}",))
         bad, seen = _scan_loads_in_flight(text.split(".amdhsa_kernel")[0])
         assert not bad, f"MSIREN_WS_ABL={abl}\n" + "\n".join(bad[:10])
+
+
+# ---- VALU-written SGPR read by a vector-memory instruction: checked on the BUILT library, every kernel --------------------
+def _sregs(tok):
+    """SGPR numbers named by one operand token ('s7', 's[26:27]', 'vcc')."""
+    tok = tok.strip()
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return list(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"s(\d+)", tok)
+    if m:
+        return [int(m.group(1))]
+    return {"vcc": [106, 107], "vcc_lo": [106], "vcc_hi": [107]}.get(tok, [])
+
+
+def _scan_valu_sgpr_to_vmem(body, need=5):
+    """gfx9: an SGPR written by a VALU instruction (v_readlane_b32 / v_readfirstlane_b32: how the compiler restores a
+    spilled pointer; VOP3 compares and carries) may be read by a vector-memory instruction only `need` wait states later.
+    The compiler pads between instructions it issues itself, but not in front of an asm statement: the weight loads of
+    siren_trunk_x1w.hip.h (asm, SGPR base) came directly behind such a restore in the fp16 instances of one build, read a
+    stale base and the launch died with an aperture violation (found with rocgdb, `set amdgpu precise-memory on`).
+    Program order, s_nop N counts N + 1.  Returns (violations, SGPR reads by vector-memory instructions seen)."""
+    wrote, state, bad, seen = {}, 0, [], 0
+    for i, raw in enumerate(body.splitlines()):
+        line = raw.split("//")[0].split(";")[0].strip()
+        if not line or line.endswith(":") or line.startswith("."):
+            continue
+        parts = line.split(None, 1)
+        op = parts[0]
+        ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        ops = [o.split()[0] if o.split() else o for o in ops]
+        if op == "s_nop":
+            state += int(ops[0], 0) + 1
+            continue
+        if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+            for o in ops:
+                for r in _sregs(o):
+                    seen += 1
+                    if r in wrote and state - wrote[r] - 1 < need:
+                        bad.append(f"`{line}` (line {i + 1}) reads s{r} {state - wrote[r] - 1} wait states after a VALU wrote it")
+        elif op.startswith("v_") and ops:
+            for o in ops[:2] if op.startswith(("v_add_co", "v_sub_co", "v_subrev_co", "v_addc", "v_subb", "v_div_scale", "v_mad_u64", "v_mad_i64")) else ops[:1]:
+                for r in _sregs(o):
+                    wrote[r] = state
+        elif op.startswith("s_") and ops and not op.startswith(("s_cmp", "s_cbranch", "s_waitcnt", "s_barrier", "s_branch", "s_bitcmp")):
+            for r in _sregs(ops[0]):
+                wrote.pop(r, None)   # (an SALU result is interlocked)
+        state += 1
+    return bad, seen
+
+
+def test_scanner_sees_a_restored_pointer_read_too_early():
+    risky = "v_readlane_b32 s0, v232, 17\nv_readlane_b32 s1, v232, 18\nglobal_load_dwordx4 a[16:19], v186, s[0:1]\n"
+    bad, seen = _scan_valu_sgpr_to_vmem(risky)
+    assert seen == 2 and len(bad) == 2
+    padded = risky.replace("global_load", "s_nop 4\nglobal_load")
+    assert _scan_valu_sgpr_to_vmem(padded) == ([], 2)
+    assert _scan_valu_sgpr_to_vmem("v_readfirstlane_b32 s4, v0\ns_add_u32 s4, s4, 16\nglobal_load_dword v1, v2, s[4:5]\n")[0] == []
+
+
+def test_no_vector_memory_instruction_of_the_built_library_reads_a_freshly_valu_written_sgpr(tmp_path):
+    """Every kernel of mri_inr_amd/libmsiren.so, as built (the gfx950 code object of its offload bundle, disassembled)."""
+    import struct
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(ROOT, "mri_inr_amd", "libmsiren.so")
+    if not (os.path.exists(objdump) and os.path.exists(lib)):
+        pytest.skip("needs the built library and llvm-objdump")
+    blob = open(lib, "rb").read()
+    at = blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert at >= 0
+    (n,), pos, elf = struct.unpack_from("<Q", blob, at + 24), at + 32, None
+    for _ in range(n):
+        off, size, tl = struct.unpack_from("<QQQ", blob, pos)
+        triple = blob[pos + 24:pos + 24 + tl].decode()
+        pos += 24 + tl
+        if "gfx950" in triple:
+            elf = blob[at + off:at + off + size]
+    assert elf, "no gfx950 code object in the library"
+    co = tmp_path / "co.elf"
+    co.write_bytes(elf)
+    res = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    kernels = re.split(r"\n(?=[0-9a-f]{16} <[^>]+>:\n)", res.stdout)[1:]
+    assert len(kernels) >= 50, len(kernels)
+    total, names = 0, []
+    for k in kernels:
+        name = re.match(r"[0-9a-f]{16} <([^>]+)>:", k).group(1)
+        bad, seen = _scan_valu_sgpr_to_vmem("\n".join(k.splitlines()[1:]))
+        assert not bad, name + "\n" + "\n".join(bad[:8])
+        total += seen
+        names.append(name)
+    assert sum("siren_trunk_x1w_kernel" in nm for nm in names) == 8 and total > 5000, (len(names), total)
