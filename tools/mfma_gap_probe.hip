@@ -1,0 +1,197 @@
+// Probe (round 4): what ONE instruction in the gap between two back-to-back v_mfma_f32_16x16x32_f16 costs the MFMA stream.
+// The weight-stationary trunk's pattern -- one wave per SIMD, 8 accumulators v[192:223], A fragments in a[0:255], 24 MFMAs per
+// k-step, 192 per slot -- with a filler behind every MFMA (or behind some of them, as the trunk's epilogue does):
+//   cycles per MFMA from s_memtime (core clock), the clock the chip held from s_memrealtime (100 MHz), wall time per launch.
+// hipcc --offload-arch=gfx950 -O3 tools/mfma_gap_probe.hip -o /tmp/gap && /tmp/gap
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define MF(VD, A, B) asm volatile("v_mfma_f32_16x16x32_f16 v[%0:%1], a[%2:%3], %4, v[%0:%1]" ::"n"(VD), "n"((VD) + 3), "n"(A), "n"((A) + 3), "v"(B))
+
+enum Filler {
+    NONE = 0,        // bare stream
+    MUL1,            // one v_mul_f32 per gap
+    MUL2,            // two
+    PKMUL1,          // one v_pk_mul_f32 per gap
+    SIN1,            // one v_sin_f32 per gap
+    EXP1,            // one v_exp_f32 per gap
+    MIX1,            // one v_fma_mixlo_f16 per gap
+    TRUNK_VALU,      // the sine trunk's 7-gap pattern: sin sin mixlo mixhi - mixlo mixhi   (112 of 192 gaps filled)
+    TRUNK_VALU_LDS,  // + 4 ds_read_b128 per k-step (B fragments of the next k-step) + 8 ds_write_b128 per slot
+    SIN_SPARSE,      // v_sin_f32 in 32 of the 192 gaps, nothing else
+    READS_ONLY,      // only the 4 ds_read_b128 per k-step
+    MORLET_PK,       // Morlet with packed multiplies: 12-gap pattern per pair: pk_mul pk_mul exp exp sin sin pk_mul mixlo mixhi - mixlo mixhi (176 of 192)
+    WRITES_ONLY,     // only the 8 ds_write_b128 per slot
+    VALU_READS,      // VALU pattern + reads, no writes
+    READS_WRITES,    // reads + writes, no VALU
+    VALU_WRITES,     // VALU pattern + writes, no reads
+    TRUNK_W64,       // as TRUNK_VALU_LDS with each 16-byte store as two ds_write_b64 (in two gaps)
+    TRUNK_CNT,       // as TRUNK_VALU_LDS, the k-step's wait counted: lgkmcnt(1) where a store follows the reads
+    NFILL
+};
+
+template <int F>
+__device__ __forceinline__ void gap(int J, float& x0, float& x1, float& y0, float& y1, unsigned& h, unsigned& l, float m, unsigned lds) {
+    (void)J;
+}
+
+#define GAP(F, J)                                                                                                       \
+    do {                                                                                                                \
+        if constexpr (F == MUL1) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(y0) : "v"(x0), "v"(m));                     \
+        if constexpr (F == MUL2) asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4" : "=&v"(y0), "=&v"(y1) : "v"(x0), "v"(x1), "v"(m)); \
+        if constexpr (F == PKMUL1) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(yy) : "v"(xx), "v"(mm));               \
+        if constexpr (F == SIN1) asm volatile("v_sin_f32 %0, %1" : "=v"(y0) : "v"(x0));                                 \
+        if constexpr (F == EXP1) asm volatile("v_exp_f32 %0, %1" : "=v"(y0) : "v"(x0));                                 \
+        if constexpr (F == MIX1) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "v"(m)); \
+        if constexpr (F == TRUNK_VALU || F == TRUNK_VALU_LDS || F == VALU_READS || F == VALU_WRITES || F == TRUNK_W64 || F == TRUNK_CNT) {                                                         \
+            constexpr int ph = (J) % 12 < 7 ? (J) % 12 : -1; /* 16 pairs x 7 gaps in 192: a pair every 12 gaps */        \
+            if constexpr (ph == 0) asm volatile("v_sin_f32 %0, %1" : "=v"(y0) : "v"(x0));                               \
+            if constexpr (ph == 1) asm volatile("v_sin_f32 %0, %1" : "=v"(y1) : "v"(x1));                               \
+            if constexpr (ph == 2) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(y0), "v"(m)); \
+            if constexpr (ph == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(y1), "v"(m)); \
+            if constexpr (ph == 5) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(l) : "v"(y0), "v"(m), "v"(h)); \
+            if constexpr (ph == 6) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(y1), "v"(m), "v"(h)); \
+        }                                                                                                               \
+        if constexpr ((F == TRUNK_VALU_LDS || F == WRITES_ONLY || F == READS_WRITES || F == VALU_WRITES || F == TRUNK_CNT) && (J) % 24 == 11) { \
+            asm volatile("ds_write_b128 %0, %1 offset:16384" : : "v"(lds), "v"(wv) : "memory");                         \
+        }                                                                                                               \
+        if constexpr (F == TRUNK_W64 && (J) % 24 == 11) asm volatile("ds_write_b64 %0, %1 offset:16384" : : "v"(lds2), "v"(wv2) : "memory"); \
+        if constexpr (F == TRUNK_W64 && (J) % 24 == 23) asm volatile("ds_write_b64 %0, %1 offset:24576" : : "v"(lds2), "v"(wv2) : "memory"); \
+        if constexpr (F == SIN_SPARSE) { if constexpr ((J) % 6 == 0) asm volatile("v_sin_f32 %0, %1" : "=v"(y0) : "v"(x0)); } \
+        if constexpr (F == MORLET_PK) {                                                                                 \
+            constexpr int ph = (J) % 12;                                                                                \
+            if constexpr (ph == 0) asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(yy) : "v"(xx));                        \
+            if constexpr (ph == 1) asm volatile("v_pk_mul_f32 %0, %1, %2" : "+v"(yy) : "v"(yy), "v"(mm));               \
+            if constexpr (ph == 2) asm volatile("v_exp_f32 %0, %1" : "=v"(e0) : "v"(yy[0]));                            \
+            if constexpr (ph == 3) asm volatile("v_exp_f32 %0, %1" : "=v"(e1) : "v"(yy[1]));                            \
+            if constexpr (ph == 4) asm volatile("v_sin_f32 %0, %1" : "=v"(y0) : "v"(x0));                               \
+            if constexpr (ph == 5) asm volatile("v_sin_f32 %0, %1" : "=v"(y1) : "v"(x1));                               \
+            if constexpr (ph == 6) asm volatile("v_mul_f32 %0, %0, %2\n\tv_mul_f32 %1, %1, %3" : "+v"(y0), "+v"(y1) : "v"(e0), "v"(e1)); \
+            if constexpr (ph == 7) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(y0), "v"(m)); \
+            if constexpr (ph == 8) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(y1), "v"(m)); \
+            if constexpr (ph == 10) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(l) : "v"(y0), "v"(m), "v"(h)); \
+            if constexpr (ph == 11) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(y1), "v"(m), "v"(h)); \
+        }                                                                                                               \
+    } while (0)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// weight fragments with bits in them: a[N] = two pseudo-random fp16 of magnitude ~0.25-1
+template <int N>
+__device__ __forceinline__ void fill_agprs(unsigned seed) {
+    if constexpr (N < 256) {
+        const unsigned v = 0x34003800u ^ ((seed * (2 * N + 1) * 2654435761u) & 0x83ff83ffu);
+        asm volatile("v_accvgpr_write_b32 a[%0], %1" : : "n"(N), "v"(v));
+        fill_agprs<N + 1>(seed);
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(256, 1) void k(float* out, int iters) {
+    asm volatile("" ::: "v255", "a255");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    fill_agprs<0>(threadIdx.x + 977u * blockIdx.x + 1u);
+    // operands with some bits in them (the chip's clock depends on what toggles)
+    u32x4 bh0, bl0, bh1, bl1;
+    for (int i = 0; i < 4; ++i) {
+        unsigned s = (threadIdx.x * 2654435761u) ^ (i * 40503u) ^ (blockIdx.x * 97u);
+        bh0[i] = 0x34003800u ^ (s & 0x03ff03ffu); bl0[i] = 0x14001800u ^ ((s >> 3) & 0x03ff03ffu);
+        bh1[i] = 0x38003400u ^ ((s >> 5) & 0x03ff03ffu); bl1[i] = 0x18001400u ^ ((s >> 7) & 0x03ff03ffu);
+    }
+    for (int i = threadIdx.x; i < 32768 / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0x34003800u ^ (i * 2654435761u & 0x03ff03ffu);
+    __syncthreads();
+    float x0 = 1e-3f * threadIdx.x, x1 = 2e-3f * threadIdx.x, y0 = 0.f, y1 = 0.f, m = 1.0009765625f, e0 = 0.f, e1 = 0.f;
+    f32x2 xx = {x0, x1}, yy = {0.f, 0.f}, mm = {m, m};
+    unsigned h = 0, l = 0;
+    const unsigned lds = (threadIdx.x & 63) * 16;
+    u32x4 rf[2][4];
+    rf[0][0] = bh0; rf[0][1] = bl0; rf[0][2] = bh1; rf[0][3] = bl1; rf[1][0] = bh0; rf[1][1] = bl0; rf[1][2] = bh1; rf[1][3] = bl1;
+    constexpr bool READS = F == TRUNK_VALU_LDS || F == READS_ONLY || F == VALU_READS || F == READS_WRITES || F == TRUNK_W64 || F == TRUNK_CNT;
+    u32x4 wv = {0x34003800u ^ threadIdx.x, 0x14001800u, 0x38003400u, 0x18001400u ^ threadIdx.x};
+    unsigned long long wv2 = 0x3400380014001800ull ^ threadIdx.x;
+    const unsigned lds2 = (threadIdx.x & 63) * 8;
+    long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#define KSTEP(S)                                                                                                        \
+    do {                                                                                                                \
+        if constexpr (READS) {                                                                                          \
+            if constexpr (F == TRUNK_CNT) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); /* the 4 reads are older than the k-step's store */ \
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+            asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8" \
+                         : "=&v"(rf[((S) + 1) & 1][0]), "=&v"(rf[((S) + 1) & 1][1]), "=&v"(rf[((S) + 1) & 1][2]), "=&v"(rf[((S) + 1) & 1][3]) \
+                         : "v"(lds), "n"(4096 * ((S) & 3)), "n"(4096 * ((S) & 3) + 1024), "n"(4096 * ((S) & 3) + 2048), "n"(4096 * ((S) & 3) + 3072) : "memory"); \
+        }                                                                                                               \
+        const u32x4 BH0 = READS ? rf[(S) & 1][0] : bh0, BL0 = READS ? rf[(S) & 1][1] : bl0;                             \
+        const u32x4 BH1 = READS ? rf[(S) & 1][2] : bh1, BL1 = READS ? rf[(S) & 1][3] : bl1;                             \
+        MF(192, 32 * (S) + 4, BH0); GAP(F, 24 * (S) + 0);  MF(196, 32 * (S) + 4, BH1); GAP(F, 24 * (S) + 1);            \
+        MF(200, 32 * (S) + 12, BH0); GAP(F, 24 * (S) + 2); MF(204, 32 * (S) + 12, BH1); GAP(F, 24 * (S) + 3);           \
+        MF(208, 32 * (S) + 20, BH0); GAP(F, 24 * (S) + 4); MF(212, 32 * (S) + 20, BH1); GAP(F, 24 * (S) + 5);           \
+        MF(216, 32 * (S) + 28, BH0); GAP(F, 24 * (S) + 6); MF(220, 32 * (S) + 28, BH1); GAP(F, 24 * (S) + 7);           \
+        MF(192, 32 * (S) + 0, BL0); GAP(F, 24 * (S) + 8);  MF(196, 32 * (S) + 0, BL1); GAP(F, 24 * (S) + 9);            \
+        MF(200, 32 * (S) + 8, BL0); GAP(F, 24 * (S) + 10); MF(204, 32 * (S) + 8, BL1); GAP(F, 24 * (S) + 11);           \
+        MF(208, 32 * (S) + 16, BL0); GAP(F, 24 * (S) + 12); MF(212, 32 * (S) + 16, BL1); GAP(F, 24 * (S) + 13);         \
+        MF(216, 32 * (S) + 24, BL0); GAP(F, 24 * (S) + 14); MF(220, 32 * (S) + 24, BL1); GAP(F, 24 * (S) + 15);         \
+        MF(192, 32 * (S) + 0, BH0); GAP(F, 24 * (S) + 16); MF(196, 32 * (S) + 0, BH1); GAP(F, 24 * (S) + 17);           \
+        MF(200, 32 * (S) + 8, BH0); GAP(F, 24 * (S) + 18); MF(204, 32 * (S) + 8, BH1); GAP(F, 24 * (S) + 19);           \
+        MF(208, 32 * (S) + 16, BH0); GAP(F, 24 * (S) + 20); MF(212, 32 * (S) + 16, BH1); GAP(F, 24 * (S) + 21);         \
+        MF(216, 32 * (S) + 24, BH0); GAP(F, 24 * (S) + 22); MF(220, 32 * (S) + 24, BH1); GAP(F, 24 * (S) + 23);         \
+    } while (0)
+        KSTEP(0); KSTEP(1); KSTEP(2); KSTEP(3); KSTEP(4); KSTEP(5); KSTEP(6); KSTEP(7);
+        x0 += 1e-3f; x1 += 2e-3f; xx[0] = x0; xx[1] = x1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    // (keep every filler result alive)
+    float keep = y0 + y1 + yy[0] + yy[1] + e0 + e1 + __uint_as_float(h) + __uint_as_float(l) + __uint_as_float(rf[0][0][0] ^ rf[1][3][3]);
+    if (keep == 123.456f) out[63] = keep;
+    if (threadIdx.x == 0 && blockIdx.x == 17) {
+        out[2 * F] = (float)(t1 - t0) / (192.0f * iters);
+        out[2 * F + 1] = (float)(t1 - t0) / (float)(r1 - r0) * 100.0f;  // MHz
+    }
+}
+
+template <int F>
+void run(float* d, int iters, const char* name) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute((const void*)k<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    float best = 1e30f, h[2 * NFILL];
+    for (int rep = 0; rep < 3; ++rep) {
+        float ms;
+        (void)hipEventRecord(e0); hipLaunchKernelGGL(k<F>, dim3(256), dim3(256), 65536, 0, d, iters); (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    (void)hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    const double tf = 256.0 * 4 * 192.0 * iters * 16 * 16 * 32 * 2 / (best * 1e-3) * 1e-12;
+    printf("%-62s %6.2f cycles per MFMA  clock %5.0f MHz  %8.3f ms  %5.0f TFLOP/s fp16 issued\n", name, h[2 * F], h[2 * F + 1], best, tf);
+}
+
+int main() {
+    float* d; (void)hipMalloc(&d, 256); (void)hipMemset(d, 0, 256);
+    const int iters = 3000;
+    for (int pass = 0; pass < 2; ++pass) {
+        printf("pass %d\n", pass);
+        run<NONE>(d, iters, "bare MFMA stream (192 per slot, trunk operand pattern)");
+        run<MUL1>(d, iters, "+ one v_mul_f32 per gap");
+        run<MUL2>(d, iters, "+ two v_mul_f32 per gap");
+        run<PKMUL1>(d, iters, "+ one v_pk_mul_f32 per gap");
+        run<SIN1>(d, iters, "+ one v_sin_f32 per gap");
+        run<EXP1>(d, iters, "+ one v_exp_f32 per gap");
+        run<MIX1>(d, iters, "+ one v_fma_mixlo_f16 per gap");
+        run<SIN_SPARSE>(d, iters, "+ v_sin_f32 in 32 of 192 gaps");
+        run<TRUNK_VALU>(d, iters, "+ the sine trunk's VALU pattern (112 of 192 gaps)");
+        run<READS_ONLY>(d, iters, "+ 4 ds_read_b128 per k-step (B from LDS), no VALU");
+        run<TRUNK_VALU_LDS>(d, iters, "+ VALU pattern + 4 ds_read_b128 / k-step + 8 ds_write_b128 / slot");
+        run<MORLET_PK>(d, iters, "+ Morlet with packed multiplies (176 of 192 gaps)");
+        run<WRITES_ONLY>(d, iters, "+ 8 ds_write_b128 per slot only");
+        run<VALU_READS>(d, iters, "+ VALU pattern + reads");
+        run<READS_WRITES>(d, iters, "+ reads + writes");
+        run<VALU_WRITES>(d, iters, "+ VALU pattern + writes");
+        run<TRUNK_W64>(d, iters, "+ VALU + reads + 16 ds_write_b64 per slot");
+        run<TRUNK_CNT>(d, iters, "+ VALU + reads + writes, k-step wait lgkmcnt(1)");
+    }
+    return 0;
+}
