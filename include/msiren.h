@@ -53,8 +53,9 @@ enum { MSIREN_ACT_SINE = 0, MSIREN_ACT_MORLET = 1 };
 /* arithmetic of the hidden-layer contractions */
 enum {
     MSIREN_PREC_F32 = 0,  /* v_mfma_f32_32x32x2_f32: exact fp32, the parity path (configs 1-4) */
-    MSIREN_PREC_BF16 = 1, /* bf16 operands, fp32 accumulate: register-resident single-product trunk,
-                             dim_hidden = 512, num_layers <= 12 (BASELINE config 5; own tolerance)  */
+    MSIREN_PREC_BF16 = 1, /* bf16 operands, fp32 accumulate: single-product trunk (weight-stationary from 3
+                             layers on), dim_hidden = 512, 2 <= num_layers <= 11: the per-layer tables must
+                             fit the 160 KB LDS (BASELINE config 5; own tolerance)                    */
     MSIREN_PREC_F16X3 = 2, /* split-fp16: 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate;
                              fp32-equivalent accuracy (22-bit operands); H = 256, 2 <= L <= 11 (the
                              per-layer tables must fit the 160 KB LDS beside the weight ring; depths

@@ -399,8 +399,10 @@ int pack_trunk_x1(msiren_ctx* h) {
     const int H = h->H, L = h->L;
     const bool bf = h->cfg.precision == MSIREN_PREC_BF16;
     if (!(h->cfg.precision == MSIREN_PREC_BF16 || h->cfg.precision == MSIREN_PREC_F16)) return 0;
-    if (H != 512 || L < 2 || L > 65 || msiren::X1nLds<3>::total(L) > 160 * 1024 || msiren::X1wLds::total(L) > 160 * 1024)
-        return fail(MSIREN_E_INVALID, "precision bf16/f16 (single-product register-resident trunk) needs dim_hidden = 512 and 2 <= num_layers with its tables fitting the 160 KB LDS; got H=%d L=%d", H, L);
+    // (the kernel launch_trunk_x1_kernel will pick: weight-stationary from 3 layers on, depths 2..11; register-resident 2..10)
+    const int lds_need = (h->x1_ws && L >= 3) ? msiren::X1wLds::total(L) : msiren::X1nLds<3>::total(L);
+    if (H != 512 || L < 2 || L > 65 || lds_need > 160 * 1024)
+        return fail(MSIREN_E_INVALID, "precision bf16/f16 (single-product trunk) needs dim_hidden = 512 and 2 <= num_layers <= 11 (10 with MSIREN_X1_WS=0): its tables must fit the 160 KB LDS; got H=%d L=%d", H, L);
     const double two_pi = 6.283185307179586476925286766559;
     const double c = (double)h->cfg.w0 / two_pi;
     std::vector<uint16_t> wpn((size_t)(L - 1) * 16 * 16 * 2 * 64 * 8), wout(512, 0);  // chunk (l, t) = [16 k-steps][2 sub-tiles][64 lanes][8]

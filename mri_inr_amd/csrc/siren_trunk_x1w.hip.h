@@ -27,6 +27,11 @@
 
 #include "siren_trunk_x1n.hip.h"  // TrunkX1Params, x1_pack2 / x1_unpack2, sum_over_q, vector types
 
+// Ablation builds (timing only, results wrong; never shipped): -DMSIREN_X1W_ABL=bitmask -- 1 no epilogue steps in the gaps,
+// 2 no slot barrier, 4 no MFMAs, 8 every layer reads layer 1's weights (an L2-resident weight stream)
+#ifndef MSIREN_X1W_ABL
+#define MSIREN_X1W_ABL 0
+#endif
 namespace msiren {
 
 struct X1wLds {  // byte offsets into dynamic LDS
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
     // Stream: block ((l - 1) * 2 + n) * 4 + wave of 64 KB = [16 k-steps][4 tiles][64 lanes][8 x 16 bit].
     const unsigned woff = (unsigned)lane * 16u;
     auto wblock = [&](int l, int n) -> const unsigned char* {
-        return reinterpret_cast<const unsigned char*>(p.wp) + ((size_t)((l - 1) * 2 + n) * 4 + wave) * 65536;
+        return reinterpret_cast<const unsigned char*>(p.wp) + ((size_t)(((MSIREN_X1W_ABL & 8) ? 0 : l - 1) * 2 + n) * 4 + wave) * 65536;  // (ablation 8: every layer reads layer 1's 512 KB -- an L2-resident weight stream)
     };
 #define MSIREN_X1W_A(S, T) (16 * (S) + 4 * (T))
 // (s_nop 4: a VALU-written SGPR -- a pointer the compiler spilled and restores with v_readlane_b32 -- may be read by a vector
@@ -252,9 +257,6 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
     // behind the MFMAs that retire them.
 // Ablation builds (timing only, results wrong; never shipped): -DMSIREN_X1W_ABL=bitmask -- 1 = no epilogue steps in the gaps,
 // 2 = no slot barrier, 4 = no MFMAs
-#ifndef MSIREN_X1W_ABL
-#define MSIREN_X1W_ABL 0
-#endif
 #define MSIREN_X1W_M(S, T, G, I, N, U, NP, UP, LASTP, GAPS)                                                            \
     do {                                                                                                               \
         if (!(MSIREN_X1W_ABL & 4)) MSIREN_X1W_MFMA(accS[(U) & 1][T][G], S, T, Bf[(S) & 1][G]);                         \

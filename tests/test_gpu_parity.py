@@ -439,6 +439,36 @@ def test_config5_16bit_trunk_vs_own_oracle(prec, res, act, tol):
     assert nerr(m32.forward_mods(mods).reshape(B, -1), ref) < 1e-4
 
 
+@pytest.mark.parametrize("L,B", [(2, 5), (3, 5), (11, 3)])
+def test_16bit_trunk_depth_range_vs_own_oracle(L, B):
+    """The single-product trunk at its depth limits: num_layers = 2 runs the register-resident kernel (the weight-stationary
+    layer pipeline needs a hidden layer in front of the final one), 3 the shortest weight-stationary pipeline, 11 the deepest
+    model whose tables fit the 160 KB LDS; 12 must be refused at load time, not at the first launch."""
+    H, Z = 512, 128
+
+    def build(depth):
+        sd = syn.make_state_dict(seed=23, dim_hidden=H, num_layers=depth, latent_dim=Z, with_encoder=False)
+        sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
+        m = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=depth, latent_dim=Z, w0=1.0, w0_initial=30.0,
+                           use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                           outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda", activation="sine",
+                           residual=True, precision="bf16")
+        m.load_state_dict(sd, strict=False)
+        m.to("cuda")
+        return sd, m
+
+    sd, m = build(L)
+    mods = syn.make_mods(9, L, B, H, lo=0.1, hi=0.6)
+    out = m.forward_mods(mods)
+    assert m.last_trunk_kernel().startswith("siren_trunk_x1n_kernel" if L == 2 else "siren_trunk_x1w_kernel"), m.last_trunk_kernel()
+    ref = orc.siren_forward(sd, mods, num_layers=L, activation="sine", residual=True, dtype=np.float64)
+    e = nerr(out.reshape(B, -1), ref)
+    assert np.isfinite(out).all() and e <= 6e-2, e
+    if L == 11:
+        with pytest.raises(ValueError, match="num_layers"):   # MSIREN_E_INVALID, with the library's message
+            build(12)
+
+
 def test_default_precision_is_the_fast_exact_trunk():
     """precision="auto" (the default) selects the f16x3 trunk where supported and must agree with the
     explicit choices bit for bit; unsupported shapes silently use the fp32 trunk."""
