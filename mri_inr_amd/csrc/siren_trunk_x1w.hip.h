@@ -128,6 +128,15 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
             asm volatile("v_mfma_f32_16x16x32_f16 %0, a[%2:%3], %1, %0" : "+v"(ACC) : "v"(B), "n"(MSIREN_X1W_A(S, T)), "n"(MSIREN_X1W_A(S, T) + 3)); \
     } while (0)
 
+// a slot's first k-step: the accumulator starts from the bias rows (C operand), no copy
+#define MSIREN_X1W_MFMA0(ACC, S, T, B, C)                                                                              \
+    do {                                                                                                               \
+        if constexpr (BF)                                                                                              \
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%3:%4], %1, %2" : "=v"(ACC) : "v"(B), "v"(C), "n"(MSIREN_X1W_A(S, T)), "n"(MSIREN_X1W_A(S, T) + 3)); \
+        else                                                                                                           \
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, a[%3:%4], %1, %2" : "=v"(ACC) : "v"(B), "v"(C), "n"(MSIREN_X1W_A(S, T)), "n"(MSIREN_X1W_A(S, T) + 3)); \
+    } while (0)
+
     // Keeping the register allocator OUT of the accumulator file: 64 placeholder values of AGPR class, defined here and used
     // behind the pass loop, keep all 256 AGPRs allocated as far as the compiler can tell (which placeholder sits in which
     // register is irrelevant: the statements above name the registers themselves; -amdgpu-spill-vgpr-to-agpr=0).
@@ -160,6 +169,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
     float part[4][2];     // last_layer dot product: [unit][column group]
     f32x4 accS[2][4][2];  // two accumulator sets: slot (l, N, U) accumulates into set U & 1 while the set of the slot before is worked off
     // the epilogue in flight (of the slot BEFORE the one whose MFMAs are being issued): a value at a time, one step per MFMA gap
+    u32x4 Bf[2][2];  // B fragments of k-steps S (parity S & 1): the next k-step's are read while this one's MFMAs run -- and a slot's
+                     // first ones during the last k-step of the slot before (PF / HAVE below)
+    f32x4 btmp[4];   // bias rows of the slot's (layer, N-pass), the C operand of its first MFMAs; fetched during the slot before
+#pragma unroll
+    for (int i = 0; i < 2; ++i) Bf[i][0] = Bf[i][1] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) btmp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float es_ = 0.f, ex_ = 0.f, ev_[2] = {0.f, 0.f};
     u32x4 eold_[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}}, enf_[2][2];  // (the next group's residual fragment is fetched while this group's is in use)
     hf4 em_[4], ew_[4];
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
         em_[T] = *reinterpret_cast<const hf4*>(pmr_ + (T) * 32);                                                       \
         if (LASTP) ew_[T] = *reinterpret_cast<const hf4*>(woutL + (NP) * 512 + (T) * 32);                              \
     } while (0)
-#define MSIREN_X1W_STEP(J, NP, UP, LASTP)                                                                              \
+#define MSIREN_X1W_STEP(J, NP, UP, LASTP, PFE)                                                                         \
     do {                                                                                                               \
         constexpr int vi_ = (J) >> 2, st_ = (J) & 3;                                                                   \
         constexpr int e_ = vi_ & 3, sub_ = (vi_ >> 2) & 1, g_ = (vi_ >> 3) & 1, kk_ = vi_ >> 4, t_ = 2 * kk_ + sub_;   \
@@ -228,6 +244,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
             if constexpr ((J) == 51 && RES) MSIREN_X1W_OLD(1, 0, NP);                                                      \
             if constexpr ((J) == 59) MSIREN_X1W_LDM(3, NP, LASTP);                                                                \
             if constexpr ((J) == 83 && RES) MSIREN_X1W_OLD(1, 1, NP);                                                      \
+            /* PFE: what the NEXT slot's gaps need first (the epilogue of THIS slot): its residual fragment (0, 0) and      \
+               modulation row 0 -- their registers are free from steps 95 / 47 on */                                       \
+            if constexpr ((PFE) && (J) == 107 && RES) eold_[0] = *reinterpret_cast<const u32x4*>(img_ + (2 * (8 * nN_ + 2 * wave + 0) + 0) * 1024); \
+            if constexpr ((PFE) && (J) == 115) {                                                                           \
+                em_[0] = *reinterpret_cast<const hf4*>(npmr_);                                                             \
+                if (nLAST_) ew_[0] = *reinterpret_cast<const hf4*>(woutL + nN_ * 512);                                     \
+            }                                                                                                              \
             if constexpr (wr_ok_) {                                                                                    \
                 if (wr_) {                                                                                             \
                     if constexpr ((J) == 11) *reinterpret_cast<u32x4*>(pimg_ + (2 * (2 * wave + 0) + 0) * 1024) = held[UP][0][0]; \
@@ -257,40 +280,64 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
     // behind the MFMAs that retire them.
 // Ablation builds (timing only, results wrong; never shipped): -DMSIREN_X1W_ABL=bitmask -- 1 = no epilogue steps in the gaps,
 // 2 = no slot barrier, 4 = no MFMAs
-#define MSIREN_X1W_M(S, T, G, I, N, U, NP, UP, LASTP, GAPS)                                                            \
+#define MSIREN_X1W_M(S, T, G, I, N, U, NP, UP, LASTP, GAPS, PF)                                                        \
     do {                                                                                                               \
-        if (!(MSIREN_X1W_ABL & 4)) MSIREN_X1W_MFMA(accS[(U) & 1][T][G], S, T, Bf[(S) & 1][G]);                         \
-        else asm volatile("" : "+v"(accS[(U) & 1][T][G]) : "v"(Bf[(S) & 1][G]));                                       \
+        if constexpr ((S) == 0) {                                                                                      \
+            if (!(MSIREN_X1W_ABL & 4)) MSIREN_X1W_MFMA0(accS[(U) & 1][T][G], S, T, Bf[(S) & 1][G], btmp[T]);           \
+            else asm volatile("" : "=v"(accS[(U) & 1][T][G]) : "v"(Bf[(S) & 1][G]), "v"(btmp[T]));                     \
+        } else {                                                                                                       \
+            if (!(MSIREN_X1W_ABL & 4)) MSIREN_X1W_MFMA(accS[(U) & 1][T][G], S, T, Bf[(S) & 1][G]);                     \
+            else asm volatile("" : "+v"(accS[(U) & 1][T][G]) : "v"(Bf[(S) & 1][G]));                                   \
+        }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if ((GAPS) && !(MSIREN_X1W_ABL & 1)) MSIREN_X1W_STEP(8 * (S) + (I), NP, UP, LASTP);                            \
+        if ((GAPS) && !(MSIREN_X1W_ABL & 1)) MSIREN_X1W_STEP(8 * (S) + (I), NP, UP, LASTP, PF);                        \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     } while (0)
-#define MSIREN_X1W_KSTEP(N, U, S, NP, UP, LASTP, GAPS, NB)                                                                       \
+#define MSIREN_X1W_KSTEP(N, U, S, NP, UP, LASTP, GAPS, NB, PF)                                                         \
     do {                                                                                                               \
         MSIREN_X1W_HOLD();                                                                                             \
         if ((U) == 0) MSIREN_X1W_WAITK(S);                                                                             \
         if ((S) < 15) {                                                                                                \
             Bf[((S) + 1) & 1][0] = *reinterpret_cast<const u32x4*>(img_ + (2 * ((S) + 1)) * 1024);                     \
             Bf[((S) + 1) & 1][1] = *reinterpret_cast<const u32x4*>(img_ + (2 * ((S) + 1) + 1) * 1024);                 \
+        } else if (PF) { /* the next slot's first fragments (its image is not being stored into: see MSIREN_X1W_LAYER) */ \
+            Bf[0][0] = *reinterpret_cast<const u32x4*>(simg_);                                                         \
+            Bf[0][1] = *reinterpret_cast<const u32x4*>(simg_ + 1024);                                                  \
+        }                                                                                                              \
+        if ((PF) && (S) == 8) { /* the next slot's bias rows (this slot's were consumed by k-step 0) */                \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) btmp[t] = *reinterpret_cast<const f32x4*>(sbias_ + t * 64);  \
         }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        MSIREN_X1W_M(S, 0, 0, 0, N, U, NP, UP, LASTP, GAPS); MSIREN_X1W_M(S, 0, 1, 1, N, U, NP, UP, LASTP, GAPS);                  \
-        MSIREN_X1W_M(S, 1, 0, 2, N, U, NP, UP, LASTP, GAPS); MSIREN_X1W_M(S, 1, 1, 3, N, U, NP, UP, LASTP, GAPS);                  \
-        MSIREN_X1W_M(S, 2, 0, 4, N, U, NP, UP, LASTP, GAPS); MSIREN_X1W_M(S, 2, 1, 5, N, U, NP, UP, LASTP, GAPS);                  \
-        MSIREN_X1W_M(S, 3, 0, 6, N, U, NP, UP, LASTP, GAPS); MSIREN_X1W_M(S, 3, 1, 7, N, U, NP, UP, LASTP, GAPS);                  \
+        MSIREN_X1W_M(S, 0, 0, 0, N, U, NP, UP, LASTP, GAPS, PF); MSIREN_X1W_M(S, 0, 1, 1, N, U, NP, UP, LASTP, GAPS, PF);          \
+        MSIREN_X1W_M(S, 1, 0, 2, N, U, NP, UP, LASTP, GAPS, PF); MSIREN_X1W_M(S, 1, 1, 3, N, U, NP, UP, LASTP, GAPS, PF);          \
+        MSIREN_X1W_M(S, 2, 0, 4, N, U, NP, UP, LASTP, GAPS, PF); MSIREN_X1W_M(S, 2, 1, 5, N, U, NP, UP, LASTP, GAPS, PF);          \
+        MSIREN_X1W_M(S, 3, 0, 6, N, U, NP, UP, LASTP, GAPS, PF); MSIREN_X1W_M(S, 3, 1, 7, N, U, NP, UP, LASTP, GAPS, PF);          \
         if ((U) == (NB) - 1) MSIREN_X1W_LOADK(S, wnext_);                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     } while (0)
 
 // LAST (compile-time): the final hidden layer -- its outputs only meet last_layer.weight (a dot product per coordinate), no
 // image is written.  LASTP: the same for the slot before.  lp_: that slot's layer (l, or l - 1 for a layer's first slot).
-#define MSIREN_X1W_SLOT(N, U, LAST, NP, UP, LASTP, GAPS, BAR, NB)                                                                     \
+// HAVE: what the slot needs first -- its bias rows, its first B fragments, and (GAPS) the first residual fragment and modulation
+// row of the epilogue it carries -- was fetched during the slot before (1; 2: if l > 1, a pass's first slot has no slot before);
+// PF: it does that for the slot after it.  PF(n) == HAVE(n + 1).  Without it every slot started with an LDS round trip in
+// front of its first MFMA and another in front of its second epilogue step.
+#define MSIREN_X1W_SLOT(N, U, LAST, NP, UP, LASTP, GAPS, BAR, NB, HAVE, PF)                                             \
     do {                                                                                                               \
+        /* the slot after this one: (N, U + 1), or (1 - N, 0) -- of the next layer behind N-pass 1 */                   \
+        constexpr int sU_ = (U) < (NB) - 1 ? (U) + 1 : 0, sN_ = (U) < (NB) - 1 ? (N) : 1 - (N);                         \
+        constexpr int sDL_ = ((U) == (NB) - 1 && (N) == 1) ? 1 : 0;                                                    \
         /* (opaque: as constants the units' offsets are folded into dozens of loop-invariant address registers) */     \
-        unsigned uoff_ = (U) * 32768u, poff_ = (UP) * 32768u;                                                          \
-        asm volatile("" : "+s"(uoff_), "+s"(poff_));                                                                   \
+        unsigned uoff_ = (U) * 32768u, poff_ = (UP) * 32768u, soff_ = sU_ * 32768u;                                    \
+        asm volatile("" : "+s"(uoff_), "+s"(poff_), "+s"(soff_));                                                      \
         unsigned char* const img_ = actL + uoff_;                                                                      \
         unsigned char* const pimg_ = actL + poff_;                                                                     \
+        [[maybe_unused]] const unsigned char* const simg_ = actL + soff_;                                              \
+        [[maybe_unused]] const unsigned char* const sbias_ = biasL + (l - 1 + sDL_) * 2048 + sN_ * 1024;               \
+        /* the epilogue of THIS slot rides in the next one's gaps: what it reads first (MSIREN_X1W_STEP, PFE) */        \
+        [[maybe_unused]] constexpr int nN_ = (N);                                                                      \
+        [[maybe_unused]] constexpr bool nLAST_ = (LAST);                                                               \
+        [[maybe_unused]] const unsigned char* const npmr_ = modsL + ((l & 1) * 4 + (U)) * 1024 + (N) * 512;            \
         const int lp_ = ((N) == 0 && (U) == 0) ? l - 1 : l;                                                            \
         const bool wr_ = lp_ >= 1; /* (a pass's first slot: nothing before it) */                                      \
         const unsigned char* const pmr_ = modsL + ((lp_ & 1) * 4 + (UP)) * 1024 + (NP) * 512;                          \
@@ -303,26 +350,22 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
             if (!(MSIREN_X1W_ABL & 2)) __builtin_amdgcn_s_barrier(); /* every wave is past the MFMAs of the slot before: its image may be updated in \
                                              place; what earlier slots' epilogues stored is complete */                \
         }                                                                                                              \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                \
-            accS[(U) & 1][t][0] = *reinterpret_cast<const f32x4*>(biasL + (l - 1) * 2048 + (N) * 1024 + t * 64);       \
-            accS[(U) & 1][t][1] = accS[(U) & 1][t][0];                                                                 \
+        if (!((HAVE) == 1 || ((HAVE) == 2 && l > 1))) {                                                                \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                              \
+                btmp[t] = *reinterpret_cast<const f32x4*>(biasL + (l - 1) * 2048 + (N) * 1024 + t * 64);               \
+            Bf[0][0] = *reinterpret_cast<const u32x4*>(img_);                                                          \
+            Bf[0][1] = *reinterpret_cast<const u32x4*>(img_ + 1024);                                                   \
+            if (GAPS) MSIREN_X1W_EPI_BEGIN(NP, UP, LASTP);                                                             \
         }                                                                                                              \
-        u32x4 Bf[2][2];                                                                                                \
-        Bf[0][0] = *reinterpret_cast<const u32x4*>(img_);                                                              \
-        Bf[0][1] = *reinterpret_cast<const u32x4*>(img_ + 1024);                                                       \
-        /* the accumulators' initial values are in place before the first (asm) MFMA reads them as its C operand */     \
-        asm volatile("s_nop 1" : "+v"(accS[(U) & 1][0][0]), "+v"(accS[(U) & 1][0][1]), "+v"(accS[(U) & 1][1][0]), "+v"(accS[(U) & 1][1][1]), \
-                     "+v"(accS[(U) & 1][2][0]), "+v"(accS[(U) & 1][2][1]), "+v"(accS[(U) & 1][3][0]), "+v"(accS[(U) & 1][3][1])); \
-        if (GAPS) MSIREN_X1W_EPI_BEGIN(NP, UP, LASTP);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        MSIREN_X1W_KSTEP(N, U, 0, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 1, NP, UP, LASTP, GAPS, NB);                            \
-        MSIREN_X1W_KSTEP(N, U, 2, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 3, NP, UP, LASTP, GAPS, NB);                            \
-        MSIREN_X1W_KSTEP(N, U, 4, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 5, NP, UP, LASTP, GAPS, NB);                            \
-        MSIREN_X1W_KSTEP(N, U, 6, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 7, NP, UP, LASTP, GAPS, NB);                            \
-        MSIREN_X1W_KSTEP(N, U, 8, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 9, NP, UP, LASTP, GAPS, NB);                            \
-        MSIREN_X1W_KSTEP(N, U, 10, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 11, NP, UP, LASTP, GAPS, NB);                          \
-        MSIREN_X1W_KSTEP(N, U, 12, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 13, NP, UP, LASTP, GAPS, NB);                          \
-        MSIREN_X1W_KSTEP(N, U, 14, NP, UP, LASTP, GAPS, NB); MSIREN_X1W_KSTEP(N, U, 15, NP, UP, LASTP, GAPS, NB);                          \
+        MSIREN_X1W_KSTEP(N, U, 0, NP, UP, LASTP, GAPS, NB, PF); MSIREN_X1W_KSTEP(N, U, 1, NP, UP, LASTP, GAPS, NB, PF);            \
+        MSIREN_X1W_KSTEP(N, U, 2, NP, UP, LASTP, GAPS, NB, PF); MSIREN_X1W_KSTEP(N, U, 3, NP, UP, LASTP, GAPS, NB, PF);            \
+        MSIREN_X1W_KSTEP(N, U, 4, NP, UP, LASTP, GAPS, NB, PF); MSIREN_X1W_KSTEP(N, U, 5, NP, UP, LASTP, GAPS, NB, PF);            \
+        MSIREN_X1W_KSTEP(N, U, 6, NP, UP, LASTP, GAPS, NB, PF); MSIREN_X1W_KSTEP(N, U, 7, NP, UP, LASTP, GAPS, NB, PF);            \
+        MSIREN_X1W_KSTEP(N, U, 8, NP, UP, LASTP, GAPS, NB, PF); MSIREN_X1W_KSTEP(N, U, 9, NP, UP, LASTP, GAPS, NB, PF);            \
+        MSIREN_X1W_KSTEP(N, U, 10, NP, UP, LASTP, GAPS, NB, PF); MSIREN_X1W_KSTEP(N, U, 11, NP, UP, LASTP, GAPS, NB, PF);          \
+        MSIREN_X1W_KSTEP(N, U, 12, NP, UP, LASTP, GAPS, NB, PF); MSIREN_X1W_KSTEP(N, U, 13, NP, UP, LASTP, GAPS, NB, PF);          \
+        MSIREN_X1W_KSTEP(N, U, 14, NP, UP, LASTP, GAPS, NB, PF); MSIREN_X1W_KSTEP(N, U, 15, NP, UP, LASTP, GAPS, NB, PF);          \
         if (GAPS) MSIREN_X1W_EPI_END(NP, UP, LASTP);                                                                   \
     } while (0)
 // A final-layer slot's own epilogue, BEHIND its MFMAs and on the accumulator set it has just filled: sine, residual, modulation
@@ -335,6 +378,10 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
         unsigned poff_ = (U) * 32768u;                                                                                 \
         asm volatile("" : "+s"(poff_));                                                                                \
         unsigned char* const pimg_ = actL + poff_;                                                                     \
+        [[maybe_unused]] unsigned char* const img_ = pimg_; /* (names MSIREN_X1W_STEP mentions under PFE, never true here) */ \
+        [[maybe_unused]] constexpr int nN_ = 0;                                                                        \
+        [[maybe_unused]] constexpr bool nLAST_ = false;                                                                \
+        [[maybe_unused]] const unsigned char* const npmr_ = modsL;                                                     \
         [[maybe_unused]] const bool wr_ = false;                                                                       \
         const unsigned char* const pmr_ = modsL + ((l & 1) * 4 + (U)) * 1024 + (N) * 512;                              \
         [[maybe_unused]] const float pwi_ = winvT[l - 1];                                                              \
@@ -345,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
     } while (0)
 // (fenced step by step: left alone the compiler issues all 32 asm sines first -- volatile statements keep their order, the rest
 // sinks below them -- and spills their results)
-#define MSIREN_X1W_F1(J, N, U) MSIREN_X1W_STEP(J, N, U, true); __builtin_amdgcn_sched_barrier(0)
+#define MSIREN_X1W_F1(J, N, U) MSIREN_X1W_STEP(J, N, U, true, false); __builtin_amdgcn_sched_barrier(0)
 #define MSIREN_X1W_F4(J, N, U) MSIREN_X1W_F1(J, N, U); MSIREN_X1W_F1(J + 1, N, U); MSIREN_X1W_F1(J + 2, N, U); MSIREN_X1W_F1(J + 3, N, U)
 #define MSIREN_X1W_F16(J, N, U) MSIREN_X1W_F4(J, N, U); MSIREN_X1W_F4(J + 4, N, U); MSIREN_X1W_F4(J + 8, N, U); MSIREN_X1W_F4(J + 12, N, U)
 // the eight slots of a layer; LASTP0: whether the slot before the layer's first one belongs to a final layer (never: a pass
@@ -357,46 +404,46 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
 // barriers of (a) lie in between for U = 0..2, and the one at (0,1) covers U = 3.  Slots (0,2), (0,3), (1,0) need none.
 #define MSIREN_X1W_LAYER()                                                                                             \
     do {                                                                                                               \
-        MSIREN_X1W_SLOT(0, 0, false, 1, 3, false, true, true, 4);                                                         \
-        MSIREN_X1W_SLOT(0, 1, false, 0, 0, false, true, true, 4);                                                         \
+        MSIREN_X1W_SLOT(0, 0, false, 1, 3, false, true, true, 4, 2, true);                                             \
+        MSIREN_X1W_SLOT(0, 1, false, 0, 0, false, true, true, 4, 1, true);                                             \
         stage_mods(l + 1); /* (no asm load is in flight here: the compiler's own wait drains nothing of ours) */       \
-        MSIREN_X1W_SLOT(0, 2, false, 0, 1, false, true, false, 4);                                                        \
-        MSIREN_X1W_SLOT(0, 3, false, 0, 2, false, true, false, 4);                                                        \
-        MSIREN_X1W_SLOT(1, 0, false, 0, 3, false, true, false, 4);                                                        \
-        MSIREN_X1W_SLOT(1, 1, false, 1, 0, false, true, true, 4);                                                         \
-        MSIREN_X1W_SLOT(1, 2, false, 1, 1, false, true, true, 4);                                                         \
-        MSIREN_X1W_SLOT(1, 3, false, 1, 2, false, true, true, 4);                                                         \
+        MSIREN_X1W_SLOT(0, 2, false, 0, 1, false, true, false, 4, 1, true);                                            \
+        MSIREN_X1W_SLOT(0, 3, false, 0, 2, false, true, false, 4, 1, true);                                            \
+        MSIREN_X1W_SLOT(1, 0, false, 0, 3, false, true, false, 4, 1, true);                                            \
+        MSIREN_X1W_SLOT(1, 1, false, 1, 0, false, true, true, 4, 1, true);                                             \
+        MSIREN_X1W_SLOT(1, 2, false, 1, 1, false, true, true, 4, 1, true);                                             \
+        MSIREN_X1W_SLOT(1, 3, false, 1, 2, false, true, true, 4, 1, true);                                             \
     } while (0)
 // the final hidden layer: its first slot still carries the layer before's last epilogue in its gaps; nothing is stored
 // into an image any more (barriers: the two that order the last in-place stores against their readers)
 #define MSIREN_X1W_FINAL_LAYER()                                                                                       \
     do {                                                                                                               \
-        MSIREN_X1W_SLOT(0, 0, true, 1, 3, false, true, true, 4);    MSIREN_X1W_FINAL_EPI(0, 0);                           \
-        MSIREN_X1W_SLOT(0, 1, true, 0, 0, true, false, true, 4);    MSIREN_X1W_FINAL_EPI(0, 1);                           \
-        MSIREN_X1W_SLOT(0, 2, true, 0, 1, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(0, 2);                           \
-        MSIREN_X1W_SLOT(0, 3, true, 0, 2, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(0, 3);                           \
-        MSIREN_X1W_SLOT(1, 0, true, 0, 3, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(1, 0);                           \
-        MSIREN_X1W_SLOT(1, 1, true, 1, 0, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(1, 1);                           \
-        MSIREN_X1W_SLOT(1, 2, true, 1, 1, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(1, 2);                           \
-        MSIREN_X1W_SLOT(1, 3, true, 1, 2, true, false, false, 4);   MSIREN_X1W_FINAL_EPI(1, 3);                           \
+        MSIREN_X1W_SLOT(0, 0, true, 1, 3, false, true, true, 4, 1, false);    MSIREN_X1W_FINAL_EPI(0, 0);              \
+        MSIREN_X1W_SLOT(0, 1, true, 0, 0, true, false, true, 4, 0, false);    MSIREN_X1W_FINAL_EPI(0, 1);              \
+        MSIREN_X1W_SLOT(0, 2, true, 0, 1, true, false, false, 4, 0, false);   MSIREN_X1W_FINAL_EPI(0, 2);              \
+        MSIREN_X1W_SLOT(0, 3, true, 0, 2, true, false, false, 4, 0, false);   MSIREN_X1W_FINAL_EPI(0, 3);              \
+        MSIREN_X1W_SLOT(1, 0, true, 0, 3, true, false, false, 4, 0, false);   MSIREN_X1W_FINAL_EPI(1, 0);              \
+        MSIREN_X1W_SLOT(1, 1, true, 1, 0, true, false, false, 4, 0, false);   MSIREN_X1W_FINAL_EPI(1, 1);              \
+        MSIREN_X1W_SLOT(1, 2, true, 1, 1, true, false, false, 4, 0, false);   MSIREN_X1W_FINAL_EPI(1, 2);              \
+        MSIREN_X1W_SLOT(1, 3, true, 1, 2, true, false, false, 4, 0, false);   MSIREN_X1W_FINAL_EPI(1, 3);              \
     } while (0)
 
 // The same for a pass of TWO units (slots (0,0) (0,1) (1,0) (1,1); the second unit's slots fetch).  Barriers: (a) (0,0) [carries
 // (l-1, 1, 1)] and (1,1) [carries (1,0)]; (b) unit 1's image is stored into during (0,0) of the next layer and read in (0,1).
 #define MSIREN_X1W_LAYER2()                                                                                            \
     do {                                                                                                               \
-        MSIREN_X1W_SLOT(0, 0, false, 1, 1, false, true, true, 2);                                                      \
-        MSIREN_X1W_SLOT(0, 1, false, 0, 0, false, true, true, 2);                                                      \
-        MSIREN_X1W_SLOT(1, 0, false, 0, 1, false, true, false, 2);                                                     \
+        MSIREN_X1W_SLOT(0, 0, false, 1, 1, false, true, true, 2, 0, false);                                            \
+        MSIREN_X1W_SLOT(0, 1, false, 0, 0, false, true, true, 2, 0, false);                                            \
+        MSIREN_X1W_SLOT(1, 0, false, 0, 1, false, true, false, 2, 0, false);                                           \
         stage_mods(l + 1); /* (behind a slot that has waited for every weight load: none of ours is in flight) */      \
-        MSIREN_X1W_SLOT(1, 1, false, 1, 0, false, true, true, 2);                                                      \
+        MSIREN_X1W_SLOT(1, 1, false, 1, 0, false, true, true, 2, 0, false);                                            \
     } while (0)
 #define MSIREN_X1W_FINAL_LAYER2()                                                                                      \
     do {                                                                                                               \
-        MSIREN_X1W_SLOT(0, 0, true, 1, 1, false, true, true, 2);    MSIREN_X1W_FINAL_EPI(0, 0);                        \
-        MSIREN_X1W_SLOT(0, 1, true, 0, 0, true, false, true, 2);    MSIREN_X1W_FINAL_EPI(0, 1);                        \
-        MSIREN_X1W_SLOT(1, 0, true, 0, 1, true, false, false, 2);   MSIREN_X1W_FINAL_EPI(1, 0);                        \
-        MSIREN_X1W_SLOT(1, 1, true, 1, 0, true, false, false, 2);   MSIREN_X1W_FINAL_EPI(1, 1);                        \
+        MSIREN_X1W_SLOT(0, 0, true, 1, 1, false, true, true, 2, 0, false);    MSIREN_X1W_FINAL_EPI(0, 0);              \
+        MSIREN_X1W_SLOT(0, 1, true, 0, 0, true, false, true, 2, 0, false);    MSIREN_X1W_FINAL_EPI(0, 1);              \
+        MSIREN_X1W_SLOT(1, 0, true, 0, 1, true, false, false, 2, 0, false);   MSIREN_X1W_FINAL_EPI(1, 0);              \
+        MSIREN_X1W_SLOT(1, 1, true, 1, 0, true, false, false, 2, 0, false);   MSIREN_X1W_FINAL_EPI(1, 1);              \
     } while (0)
 
     for (int pass = 0; (unsigned)cur_pass < npasses; ++pass) {

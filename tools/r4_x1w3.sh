@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r4/x1w3
 rm -rf $out && mkdir -p $out
-timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_multi.py -x -q -k "config5 or residual or deep_model or single_gpu_line" > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $out/pytest.log
+timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_multi.py -x -q -k "config5 or residual or deep_model or single_gpu_line or 16bit_trunk_depth" > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $out/pytest.log
 run() { name=$1; shift; timeout -k 10 300 python3 bench.py "$@" > $out/$name.json 2> $out/$name.err || { echo "$name failed"; tail -3 $out/$name.err; }; }
 for r in 1 2; do
   run x1w_r$r --model deep_residual --precision bf16 --no-cpu-baseline --check --steps 300
