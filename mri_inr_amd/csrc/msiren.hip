@@ -117,6 +117,8 @@ struct msiren_ctx {
     void *d_woutx1 = nullptr, *d_wpx1n = nullptr;  // last_layer.weight (fp16); weight stream of siren_trunk_x1n.hip.h
     void* d_wpx1w = nullptr;       // weight stream of siren_trunk_x1w.hip.h (weight-stationary: 64 KB per layer, N-pass and wave)
     int x1_ws = 1;                 // MSIREN_X1_WS=0: the register-resident kernel (A/B knob, read at create)
+    int x1_grid = 0;               // MSIREN_X1_GRID=n: cap on the config-5 trunk's grid (experiments)
+    int x1_balance = 1;            // MSIREN_X1_BALANCE=0: the weight-stationary config-5 trunk on every CU (A/B knob; x1w_balanced_grid)
     int lds_attr_x1w = 0;
 
     float* d_bias32x1 = nullptr;   // bias rows: fp32, in revolutions x the layer's weight scale
@@ -853,7 +855,11 @@ int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_
     p.total_units = (int)units;
     p.plan = h->plan;
     const bool ws = h->x1_ws && h->L >= 3;
-    const int grid = (int)std::min<int64_t>(h->num_cus, (units + 3) / 4);
+    // (one-stream handles: the balanced grid -- the same rounds on fewer CUs, 1 % faster alone; two streams: every CU, so that the
+    //  next call's trunk can start in the half-empty last round -- measured 111.2 against 109.3 Mpixel/s, profiles/r4/09_*)
+    const int cus_x1 = h->x1_grid > 0 ? std::min(h->x1_grid, h->num_cus) : h->num_cus;
+    const bool balance = ws && h->x1_balance && (h->nstreams == 1 || h->solo);
+    const int grid = balance ? msiren::x1w_balanced_grid(units, cus_x1) : (int)std::min<int64_t>(cus_x1, (units + 3) / 4);
     // (the weight-stationary kernel lays its passes out itself: x1w_schedule, 4-unit passes and a last round of 2-unit ones)
     msiren::X1wSchedule sch = msiren::x1w_schedule(units, grid);
     const int64_t npasses = ws ? (int64_t)sch.n4 + sch.n2 : (units + 3) / 4;
@@ -1403,6 +1409,8 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_QUEUE_START")) h->queue_start = (unsigned)std::strtoul(e, nullptr, 0);
     if (const char* e = std::getenv("MSIREN_F16_WS")) h->f16_ws = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_X1_WS")) h->x1_ws = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_X1_BALANCE")) h->x1_balance = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_X1_GRID")) h->x1_grid = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_RANGE_RERUN")) h->cond_rerun = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_SPLIT_MIN")) h->split_min = std::max<long long>(0, std::atoll(e));
     if (const char* e = std::getenv("MSIREN_LINEAR_TILE_MIN")) h->lin_tile_min = std::max(0, std::atoi(e));

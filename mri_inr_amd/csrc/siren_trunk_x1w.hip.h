@@ -59,6 +59,24 @@ __host__ __device__ inline X1wSchedule x1w_schedule(long long units, int grid) {
     return s;
 }
 
+// Host: the SMALLEST grid (down to 7/8 of the CUs) that needs no more rounds than all CUs would.  A workgroup owns its CU (512
+// registers, 158 KB LDS), so whatever the launch leaves free is where the other stream's encoder / Modulator kernels of the next
+// call run meanwhile: one 320x320 slice = 450 passes = two rounds on 256 CUs (the second 3/4 full) and also on 225 -- the same
+// launch time, and 31 CUs for the neighbour instead of a queue behind the trunk.
+inline int x1w_balanced_grid(long long units, int cus) {
+    const long long passes4 = (units + 3) / 4;
+    if (passes4 <= cus) return (int)(passes4 < 1 ? 1 : passes4);
+    auto half_rounds = [&](int g) {
+        const X1wSchedule s = x1w_schedule(units, g);
+        return 2LL * ((s.n4 + g - 1) / g) + (s.n2 + g - 1) / g;
+    };
+    const long long c0 = half_rounds(cus);
+    int best = cus;
+    for (int g = cus - 1; g >= cus - cus / 8; --g)
+        if (half_rounds(g) <= c0) best = g;
+    return best;
+}
+
 template <int BF, int ACT, int RES>
 __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p) {
     using LY = X1wLds;
