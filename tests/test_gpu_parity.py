@@ -469,6 +469,35 @@ def test_16bit_trunk_depth_range_vs_own_oracle(L, B):
             build(12)
 
 
+def test_config5_batch_invariance_over_pass_shapes():
+    """A tile's output must not depend on the batch it came in (modulated_siren.py:435-457: patches are independent) -- bit for
+    bit, whatever mix of 4-unit passes, 2-unit tail passes (x1w_schedule) and grid (x1w_balanced_grid) the launch is made of:
+    1 tile = 18 units (4 + 1 passes), 57 tiles = 1026 units (one full round + a single 2-unit pass), 58 = 1044 (+ 10 of them),
+    129 = 2322 units (two full rounds + 137 tail passes), 460 tiles = 8 rounds + a tail; one and two streams."""
+    H, L, Z, B = 512, 10, 128, 460
+    sd = syn.make_state_dict(seed=21, dim_hidden=H, num_layers=L, latent_dim=Z, with_encoder=False)
+    sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
+    m = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=1.0, w0_initial=30.0,
+                       use_bias=True, dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None,
+                       outer_patch_size=32, inner_patch_size=16, siren_patch_size=24, device="cuda", activation="sine",
+                       residual=True, precision="bf16")
+    m.load_state_dict(sd, strict=False)
+    m.to("cuda")
+    mods = syn.make_mods(31, L, B, H, lo=0.1, hi=0.6)
+    whole = m.forward_mods(mods)
+    assert m.last_trunk_kernel().startswith("siren_trunk_x1w_kernel") and np.isfinite(whole).all()
+    ref = orc.siren_forward(sd, mods[:, :3], num_layers=L, activation="sine", residual=True, dtype=np.float64)
+    assert nerr(whole[:3].reshape(3, -1), ref) <= 6e-2
+    from mri_inr_amd import _lib
+    for streams in (1, 2):
+        _lib.check(m._lib.msiren_set_streams(m._h, streams))
+        for b in (1, 2, 7, 57, 58, 129, 256, 257):
+            part = m.forward_mods(np.ascontiguousarray(mods[:, :b]))
+            assert np.array_equal(part, whole[:b]), (streams, b)
+            tail = m.forward_mods(np.ascontiguousarray(mods[:, B - b:]))
+            assert np.array_equal(tail, whole[B - b:]), (streams, b)
+
+
 def test_default_precision_is_the_fast_exact_trunk():
     """precision="auto" (the default) selects the f16x3 trunk where supported and must agree with the
     explicit choices bit for bit; unsupported shapes silently use the fp32 trunk."""
