@@ -84,6 +84,7 @@ struct msiren_ctx {
     int64_t split_min = 3200;  // MSIREN_SPLIT_MIN: *_dev forward calls of at least this many tiles are cut in two (0 = never)
     int split_pct = 12;        // MSIREN_SPLIT_PCT: share of the first part, percent
     int lin_tile_min = 1024;   // MSIREN_LINEAR_TILE_MIN: rows from which the Linear layers use the 32 x 32-tile kernel (0 = never)
+    bool lin_tile_env = false; // (set by the knob: then it holds for every layer width)
     char last_trunk[96] = "";  // name of the trunk instance launched last (msiren_last_trunk_kernel)
     const int* plan = nullptr;  // device-side list of non-black patches in effect (slice pipeline only)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1029,7 +1030,10 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
 // half the operand bytes per FLOP).  Same arithmetic either way -- an output does not depend on the batch it came in.
 int launch_linear(msiren_ctx* h, const msiren::ModulatorMfmaParams& mp) {
     hipStream_t s = h->sc[h->cur].s;
-    if (h->lin_tile_min > 0 && mp.B >= h->lin_tile_min) {
+    // (default threshold: 1024 rows; a quarter of it for layers of >= 512 outputs -- at 400 rows the 16 x 16 kernel launches 800 workgroups
+    //  per 512-wide layer and takes 10.8 us, the tiled one is 1.7 % of a config-5 step faster; 256-wide layers: 2.7 % slower.  Same bits.)
+    const int tile_min = h->lin_tile_env || mp.H < 512 ? h->lin_tile_min : h->lin_tile_min / 4;
+    if (h->lin_tile_min > 0 && mp.B >= tile_min) {
         dim3 grid((unsigned)((mp.B + 31) / 32), (unsigned)((mp.H + 31) / 32));
         hipLaunchKernelGGL((msiren::linear_mfma_tile_kernel<2, 2>), grid, dim3(256), 0, s, mp);
     } else {
@@ -1413,7 +1417,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_X1_GRID")) h->x1_grid = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_RANGE_RERUN")) h->cond_rerun = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_SPLIT_MIN")) h->split_min = std::max<long long>(0, std::atoll(e));
-    if (const char* e = std::getenv("MSIREN_LINEAR_TILE_MIN")) h->lin_tile_min = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("MSIREN_LINEAR_TILE_MIN")) { h->lin_tile_min = std::max(0, std::atoi(e)); h->lin_tile_env = true; }
     if (const char* e = std::getenv("MSIREN_SPLIT_PCT")) h->split_pct = std::max(1, std::min(90, std::atoi(e)));
     if (const char* e = std::getenv("MSIREN_TRACE_HOST")) h->trace_host = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_HOST_SPLIT")) h->host_first_pct = std::max(5, std::min(95, std::atoi(e)));

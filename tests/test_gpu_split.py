@@ -143,7 +143,7 @@ def test_full_slice_reconstruct_vs_fp64_oracle():
         assert np.array_equal(o.numpy()[0], rec)
 
 
-@pytest.mark.parametrize("H,Z,L,B", [(256, 256, 5, 1100), (256, 256, 5, 1037), (64, 48, 3, 1030), (48, 16, 2, 1025), (512, 128, 10, 1056)])
+@pytest.mark.parametrize("H,Z,L,B", [(256, 256, 5, 1100), (256, 256, 5, 1037), (64, 48, 3, 1030), (48, 16, 2, 1025), (512, 128, 10, 1056), (512, 128, 3, 300)])
 def test_tiled_linear_layers_same_bits_as_the_16x16_kernel(H, Z, L, B):
     """Throughput sizes run conv3, Linear(64, Z) and the Modulator layers on 32 x 32 output tiles
     (linear_mfma_tile_kernel<2, 2>), latency sizes on 16 x 16: same MFMA chains, same K split, same reduction order --
@@ -154,7 +154,7 @@ def test_tiled_linear_layers_same_bits_as_the_16x16_kernel(H, Z, L, B):
     mk = dict(H=H, L=L, Z=Z, precision="fp32")
     small = make_with_env(sd, {"MSIREN_LINEAR_TILE_MIN": 0}, **mk)
     tiled = make_with_env(sd, {"MSIREN_LINEAR_TILE_MIN": 1}, **mk)
-    auto = make_model(sd, **mk)   # default threshold: 1024 rows
+    auto = make_model(sd, **mk)   # default threshold: 1024 rows (256 for layers of >= 512 outputs)
     tiles = np.random.default_rng(B).random((B, 32, 32), dtype=np.float32)
     z = small.encoder(tiles)
     assert np.array_equal(tiled.encoder(tiles), z) and np.array_equal(auto.encoder(tiles), z)
