@@ -482,6 +482,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     f32x4 em0_[4];        // layer-0 modulation row of the unit being produced (final slots)
     float part[2] = {0.f, 0.f};
     float sv0_ = 0.f, sv1_ = 0.f;
+    [[maybe_unused]] float mt0_ = 0.f, mt1_ = 0.f;  // Morlet: cg r^2 -> exp2(cg r^2) of the two elements in flight
     f32x4 raw0[4][2];     // layer-0 table values of the unit being produced (final slots)
     unsigned l0h_[4], l0l_[4];
 #define MSIREN_WS_LD_EM(T) em[T] = *reinterpret_cast<const f32x4*>(emr_ + (T) * 64)
@@ -508,6 +509,21 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(192))) void 
     do {                                                                                                             \
         if constexpr (ACT == 0) asm volatile("v_sin_f32 %0, v[%1]" : "=v"(sv1_) : "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH) + 1)); \
     } while (0)
+// Morlet in a NORMAL slot (round 4): the same ten instructions, in activate<1>'s order per element, over seven gaps -- a pair of
+// plain multiplies or ONE transcendental per gap (either is free beside an MFMA, ten in one gap are not: tools/mfma_gap_probe.hip);
+// the transcendentals' results are read a gap (an MFMA) later at the earliest.  Final-layer slots keep the compact form above
+// (their gaps are taken by the layer-0 work of the next pass).
+#define MSIREN_WS_MO_M0(T, G, HH)                                                                                    \
+    asm volatile("v_mul_f32 %0, %2, v[%3]\n\tv_mul_f32 %1, %2, v[%4]" : "=&v"(mt0_), "=&v"(mt1_)                     \
+                 : "v"(p.cg), "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH)), "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH) + 1))
+#define MSIREN_WS_MO_M1(T, G, HH)                                                                                    \
+    asm volatile("v_mul_f32 %0, %0, v[%2]\n\tv_mul_f32 %1, %1, v[%3]" : "+v"(mt0_), "+v"(mt1_)                       \
+                 : "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH)), "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH) + 1))
+#define MSIREN_WS_MO_E0() asm volatile("v_exp_f32 %0, %0" : "+v"(mt0_))
+#define MSIREN_WS_MO_E1() asm volatile("v_exp_f32 %0, %0" : "+v"(mt1_))
+#define MSIREN_WS_MO_S0(T, G, HH) asm volatile("v_sin_f32 %0, v[%1]" : "=v"(sv0_) : "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH)))
+#define MSIREN_WS_MO_S1(T, G, HH) asm volatile("v_sin_f32 %0, v[%1]" : "=v"(sv1_) : "n"(MSIREN_WS_V(PP_, T, G) + 2 * (HH) + 1))
+#define MSIREN_WS_MO_P() asm volatile("v_mul_f32 %0, %0, %2\n\tv_mul_f32 %1, %1, %3" : "+v"(sv0_), "+v"(sv1_) : "v"(mt0_), "v"(mt1_))
 #define MSIREN_WS_MIXH0(DST, A, M) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(DST) : "v"(A), "v"(M))
 #define MSIREN_WS_MIXH1(DST, A, M) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(DST) : "v"(A), "v"(M))
 #define MSIREN_WS_MIXL0(DST, A, M, HI) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(DST) : "v"(A), "v"(M), "v"(HI))

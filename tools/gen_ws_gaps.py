@@ -44,6 +44,32 @@ for g, u in ((0, 0), (1, 0), (0, 1), (1, 1)):
     put(A, j + 28, f"MSIREN_WS_STORE_PIECE(ehu[{g}][{u}], elu[{g}][{u}], {u}, {g})")
     j += 29
 
+# ---- normal slot, Morlet (ACT == 1): the same 16 half accumulators, 9 gaps each -- the ten instructions of sin(2 pi r) exp2(cg r^2)
+# a pair of plain multiplies or ONE transcendental per gap (both free beside an MFMA: tools/mfma_gap_probe.hip) instead of all ten
+# in one gap, the hi / lo splits as pairs
+A1 = {}
+
+
+def half_a1(j0, t, g, hh, last=False):
+    e = f"[{g}]{idx(t, hh)}"
+    put(A1, j0, f"MSIREN_WS_MO_M0({t}, {g}, {hh})")
+    put(A1, j0 + 1, f"MSIREN_WS_MO_M1({t}, {g}, {hh})")
+    put(A1, j0 + 2, "MSIREN_WS_MO_E0()")
+    put(A1, j0 + 3, "MSIREN_WS_MO_E1()")
+    put(A1, j0 + 4, f"MSIREN_WS_MO_S0({t}, {g}, {hh})")
+    put(A1, j0 + 5, f"MSIREN_WS_MO_S1({t}, {g}, {hh})")
+    put(A1, j0 + 6, "MSIREN_WS_MO_P()")
+    put(A1, j0 + 7, f"MSIREN_WS_MIXH01(ehu{e}, sv0_, em[{t}][{2 * hh}], sv1_, em[{t}][{2 * hh + 1}])")
+    put(A1, j0 + 8, f"MSIREN_WS_MIXL01{'_LAST' if last else ''}(elu{e}, sv0_, em[{t}][{2 * hh}], sv1_, em[{t}][{2 * hh + 1}], ehu{e})")
+
+
+j = 8
+for g, u in ((0, 0), (1, 0), (0, 1), (1, 1)):
+    for k, (t, hh) in enumerate(((2 * u, 0), (2 * u, 1), (2 * u + 1, 0), (2 * u + 1, 1))):
+        half_a1(j + 9 * k, t, g, hh, last=(k == 3))
+    put(A1, j + 36, f"MSIREN_WS_STORE_PIECE(ehu[{g}][{u}], elu[{g}][{u}], {u}, {g})")
+    j += 37
+
 # ---- final slot ----
 # (mw[t]: the final row of the modulation table = modulation x last_layer.weight, read at the start of region 0)
 j = 8
@@ -97,8 +123,12 @@ def place_reads(tab):
     for s in range(8):
         cand = [24 * s + i for i in (2, 4, 6, 8, 10, 12, 14, 16)]
         free = [g for g in cand if g not in tab]
-        plain = [g for g in cand if g in tab and not any(("_S0(" in st or "_S1(" in st or "RED" in st or "STORE" in st or "WAIT" in st or "FIN" in st) for st in tab[g])]
-        chosen = sorted((free + plain)[:4])
+        busy = ("_S0(" , "_S1(", "_MO_E", "RED", "STORE", "WAIT", "FIN")
+        plain = [g for g in cand if g in tab and not any(any(b in st for b in busy) for st in tab[g])]
+        # (Morlet: where a region has fewer than four such gaps, an odd gap without a transcendental takes a read -- normal
+        #  slots that carry weight loads there are the fourth unit's only)
+        odd = [24 * s + i for i in (9, 11, 13, 15) if not any(any(b in st for b in busy) for st in tab.get(24 * s + i, []))]
+        chosen = sorted((free + plain + odd)[:4])
         assert len(chosen) == 4, (s, free, plain)
         for g, frag in zip(chosen, (0, 2, 1, 3)):
             tab.setdefault(g, []).append(f"MSIREN_WS_BREAD({s}, {frag})")
@@ -106,6 +136,7 @@ def place_reads(tab):
 
 if SPREAD:
     place_reads(A)
+    place_reads(A1)
     place_reads(B)
 
 # region 7 of a final slot (behind the barrier): finish the prev final slot's output
@@ -115,10 +146,18 @@ with open(OUT, "w") as f:
     f.write("// GENERATED by tools/gen_ws_gaps.py -- the epilogue schedule of siren_trunk_f16x3w.hip.h, one macro per MFMA gap\n"
             "// (region S = k-step, MFMA i of its 24): MSIREN_WS_GA_S_i for a normal slot, MSIREN_WS_GB_S_i for a final-layer slot.\n"
             "#pragma once\n")
-    for name, tab in (("GA", A), ("GB", B)):
-        for s in range(8):
-            for i in range(24):
-                st = tab.get(24 * s + i, [])
-                body = "; ".join(st)
-                f.write(f"#define MSIREN_WS_{name}_{s}_{i}(FL) do {{ {body}; }} while (0)\n" if st else f"#define MSIREN_WS_{name}_{s}_{i}(FL) do {{}} while (0)\n")
-print("wrote", OUT, "gaps used: A", len(A), "B", len(B), "last A", max(A), "last B", max(B))
+    for s in range(8):
+        for i in range(24):
+            st0, st1 = A.get(24 * s + i, []), A1.get(24 * s + i, [])
+            if st0 == st1:
+                body = "; ".join(st0)
+                f.write(f"#define MSIREN_WS_GA_{s}_{i}(FL) do {{ {body}; }} while (0)\n" if st0 else f"#define MSIREN_WS_GA_{s}_{i}(FL) do {{}} while (0)\n")
+            else:
+                b0, b1 = "; ".join(st0), "; ".join(st1)
+                f.write(f"#define MSIREN_WS_GA_{s}_{i}(FL) do {{ if constexpr (ACT == 0) {{ {b0}; }} else {{ {b1}; }} }} while (0)\n")
+    for s in range(8):
+        for i in range(24):
+            st = B.get(24 * s + i, [])
+            body = "; ".join(st)
+            f.write(f"#define MSIREN_WS_GB_{s}_{i}(FL) do {{ {body}; }} while (0)\n" if st else f"#define MSIREN_WS_GB_{s}_{i}(FL) do {{}} while (0)\n")
+print("wrote", OUT, "gaps used: A", len(A), "A1 (Morlet)", len(A1), "B", len(B), "last A", max(A), "last A1", max(A1), "last B", max(B))
