@@ -215,3 +215,7 @@ def test_config5_masked_slice_pipeline_same_bits_as_step_by_step():
     # and again right away: the pass counter was left where the next launch expects it
     assert np.array_equal(m.reconstruct(imgs), rec)
     assert np.array_equal(m(kept[:57]), full[[i for i in range(tiles.shape[0]) if i not in set(black)][:57]])
+    # nothing but black tiles: the trunk is launched on an upper bound and finds zero units to do
+    assert not m.reconstruct(np.zeros((2, 320, 320), np.float32)).any()
+    assert np.array_equal(m.reconstruct(imgs), rec)
+    assert m(np.zeros((0, 32, 32), np.float32)).shape == (0, 24, 24)
