@@ -75,5 +75,24 @@ for cfg in ("sine", "morlet", "config5_bf16"):
         it += 1
     print(f"{cfg}: {launches} calls in {secs:.0f} s, {bad} mismatches, last trunk {m.last_trunk_kernel()}", flush=True)
     ok = ok and bad == 0
+    # the slice pipeline (black-tile filter on the device: the trunk learns its tile count from the plan): random runs of masked
+    # slices against each slice reconstructed alone
+    imgs = np.stack([syn.make_slice(k, 320, 320, brain_mask=True) for k in range(10)])
+    d_i = m.device_array(imgs.shape).copy_from(imgs)
+    d_r = m.device_array(imgs.shape)
+    alone = np.stack([m.reconstruct(imgs[k]) for k in range(10)])
+    t_end, calls, bad = time.time() + secs / 3, 0, 0
+    while time.time() < t_end:
+        _lib.check(m._lib.msiren_set_streams(m._h, int(rng.integers(1, 3))))
+        n = int(rng.integers(1, 7))
+        o = int(rng.integers(0, 10 - n + 1))
+        _lib.check(m._lib.msiren_reconstruct_slices_dev(m._h, d_i.ptr + o * 320 * 320 * 4, n, 320, 320, d_r.ptr))
+        m.sync()
+        calls += 1
+        if not np.array_equal(d_r.numpy()[:n], alone[o:o + n]):
+            bad += 1
+            print(f"  MISMATCH {cfg}: reconstruct slices {o}..{o + n - 1}", flush=True)
+    print(f"{cfg}: {calls} slice-pipeline calls in {secs / 3:.0f} s, {bad} mismatches", flush=True)
+    ok = ok and bad == 0
 print("SOAK OK" if ok else "SOAK FAILED")
 sys.exit(0 if ok else 1)
