@@ -36,16 +36,22 @@ template __global__ void msiren::siren_trunk_f16x3w_kernel<1, 4, 0>(msiren::Trun
 """
 
 
-def _regs(tok):
-    """VGPR numbers named by one operand token ('v12', 'v[8:11]', 'v[0xc0:0xc3]', '-v7', 'v[0xe0]')."""
+def _regs(tok, agprs=False):
+    """VGPR numbers named by one operand token ('v12', 'v[8:11]', 'v[0xc0:0xc3]', '-v7', 'v[0xe0]'); with agprs=True also the
+    accumulation registers ('a7', 'a[16:19]'), numbered from 1000."""
     tok = tok.strip().lstrip("-|")
-    m = re.fullmatch(r"v\[(0x[0-9a-f]+|\d+)(?::(0x[0-9a-f]+|\d+))?\]\|?", tok)
+    m = re.fullmatch(r"([va])\[(0x[0-9a-f]+|\d+)(?::(0x[0-9a-f]+|\d+))?\]\|?", tok)
     if m:
-        lo = int(m.group(1), 0)
-        hi = int(m.group(2), 0) if m.group(2) else lo
-        return list(range(lo, hi + 1))
-    m = re.fullmatch(r"v(\d+)\|?", tok)
-    return [int(m.group(1))] if m else []
+        if m.group(1) == "a" and not agprs:
+            return []
+        base = 1000 if m.group(1) == "a" else 0
+        lo = int(m.group(2), 0)
+        hi = int(m.group(3), 0) if m.group(3) else lo
+        return list(range(base + lo, base + hi + 1))
+    m = re.fullmatch(r"([va])(\d+)\|?", tok)
+    if not m or (m.group(1) == "a" and not agprs):
+        return []
+    return [(1000 if m.group(1) == "a" else 0) + int(m.group(2))]
 
 
 def _scan(body, asm_mfma):
@@ -145,14 +151,17 @@ def test_wait_states_around_asm_issued_instructions(trunk_isa):
     assert total > 3000
 
 
-def _scan_loads_in_flight(body):
+def _scan_loads_in_flight(body, agprs=False):
     """Every vector-memory operation that returns data into VGPRs must be covered by an s_waitcnt vmcnt BEFORE anything
     reads or overwrites its destination.  The compiler guarantees that for loads it issues itself; for loads issued
     through asm (the weight-stationary trunk's table, modulation and queue loads) it only holds while every such asm
     statement is followed by a wait that carries the destination as an operand -- otherwise the registers are dead on
     arrival and get handed on while the data is still in flight, which is how round 3's -DMSIREN_WS_ABL=15 build faulted
     (siren_trunk_f16x3w.hip.h, "Ablation builds").  Program order; vmcnt(N) retires all but the N youngest operations
-    (in-order return on gfx9); an unconditional branch ends the path.  Returns (violations, loads seen)."""
+    (in-order return on gfx9); an unconditional branch ends the path.  agprs=True tracks loads into the accumulation registers
+    as well (the config-5 kernel's weight fragments) -- only meaningful where the code is laid out in execution order: the
+    walk is linear, and the split-fp16 weight-stationary kernel jumps between slot bodies whose text order is not their
+    execution order.  Returns (violations, loads seen)."""
     out, bad, seen = [], [], 0   # outstanding operations, oldest first: [line, text, set of destination VGPRs]
     for i, raw in enumerate(body.splitlines()):
         line = raw.split(";")[0].strip()
@@ -171,7 +180,7 @@ def _scan_loads_in_flight(body):
         if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
             out = []
             continue
-        touched = set(r for o in ops for r in _regs(o))
+        touched = set(r for o in ops for r in _regs(o, agprs=agprs))
         for rec in out:
             hit = touched & rec[2]
             if hit:
@@ -180,7 +189,7 @@ def _scan_loads_in_flight(body):
         if op.startswith(("global_", "buffer_", "flat_")):
             returns = (op.startswith(("global_load", "buffer_load", "flat_load")) and "_lds_" not in op) or \
                       (op.startswith("global_atomic") and "sc0" in raw)   # (global_load_lds_*: the VGPR operand is the address)
-            dst = set(_regs(ops[0])) if (returns and ops and ops[0].startswith("v")) else set()
+            dst = set(_regs(ops[0], agprs=agprs)) if (returns and ops and ops[0].startswith(("v", "a") if agprs else "v")) else set()
             seen += bool(dst)
             out.append([i, raw, dst])
     return bad, seen
@@ -291,3 +300,27 @@ def test_no_vector_memory_instruction_of_the_built_library_reads_a_freshly_valu_
         total += seen
         names.append(name)
     assert sum("siren_trunk_x1w_kernel" in nm for nm in names) == 8 and total > 5000, (len(names), total)
+
+
+def test_config5_weight_stationary_kernel_waits_and_distances(tmp_path):
+    """siren_trunk_x1w.hip.h issues its MFMAs and its weight loads (straight into a[0:255]) through asm and waits for the fragments
+    with counted vmcnt, k-step by k-step: every load's destination must be covered by a wait before an MFMA reads it, and every
+    accumulator must be old enough when the epilogue (plain C++, which the compiler cannot pad against asm MFMAs) reads it."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    tu = ('#include <hip/hip_runtime.h>\n#include "siren_trunk_x1w.hip.h"\n'
+          "template __global__ void msiren::siren_trunk_x1w_kernel<1, 0, 1>(msiren::TrunkX1Params);\n"
+          "template __global__ void msiren::siren_trunk_x1w_kernel<0, 1, 0>(msiren::TrunkX1Params);\n")
+    text = _compile(tmp_path, tu, "x1w")
+    kernels = re.split(r"\n(?=_ZN6msiren\d+siren_trunk_x1w_kernel)", text)[1:]
+    assert len(kernels) == 2
+    for k in kernels:
+        name, body = k.split(":")[0], k.split(".amdhsa_kernel")[0]
+        bad, seen = _scan_loads_in_flight(body, agprs=True)
+        assert not bad, name + "\n" + "\n".join(bad[:10])
+        assert seen >= 600, (name, seen)    # 64 fragment loads per (layer, N-pass) code instance, all into AGPRs
+        bad, checked, closest = _scan(body, True)
+        print(f"{name}: {seen} loads, {checked} reads of MFMA results, closest {closest} wait states")
+        assert not bad and checked > 1000 and closest >= MIN_MFMA_TO_VALU, (name, checked, closest, bad[:5])
+        bad, reads = _scan_valu_sgpr_to_vmem(body)
+        assert not bad and reads > 500, (name, reads, bad[:5])
