@@ -33,11 +33,6 @@ enum Filler {
     NFILL
 };
 
-template <int F>
-__device__ __forceinline__ void gap(int J, float& x0, float& x1, float& y0, float& y1, unsigned& h, unsigned& l, float m, unsigned lds) {
-    (void)J;
-}
-
 #define GAP(F, J)                                                                                                       \
     do {                                                                                                                \
         if constexpr (F == MUL1) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(y0) : "v"(x0), "v"(m));                     \
