@@ -130,7 +130,7 @@ class MsirenRangeError(MsirenError, FloatingPointError):
 
 def build(verbose: bool = False) -> str:
     """Compile libmsiren.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    cmd = ["make", "-j", str(min(8, os.cpu_count() or 1)), "-C", os.path.join(_HERE, "csrc")]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)

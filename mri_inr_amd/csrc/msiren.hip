@@ -23,6 +23,7 @@
 
 #include "../../include/msiren.h"
 #include "encoder_modulator.hip.h"
+#include "encoder_modulator_f16x3.hip.h"
 #include "mfma_probe.hip.h"
 #include "pass_queue.h"
 #include "weights_blob.h"
@@ -33,6 +34,7 @@
 #include "siren_trunk_x1n.hip.h"
 #include "siren_trunk_x1w.hip.h"
 #include "tiling.hip.h"
+#include "trunk_instances.h"  // the trunk kernels are compiled in their own translation units (k_*.hip)
 
 namespace {
 
@@ -71,6 +73,7 @@ struct msiren_ctx {
     struct StreamCtx {
         hipStream_t s = nullptr;
         DevBuf mods, modpad, latent, patches, keep, rec, queue, feat, plan;
+        DevBuf cscratch;  // split-fp16 Modulator: the latent part of layers 1.., lane-private (encoder_modulator_f16x3.hip.h)
         DevBuf mods2;  // a split call's second part: modulations written on the OTHER stream, read by this stream's trunk
         hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // split call: start of the call -> helper stream; helper's prologue -> this stream
         msiren::PassQueue pq;  // host view of the never-reset pass counter (pass_queue.h)
@@ -81,6 +84,7 @@ struct msiren_ctx {
     // which split-fp16 trunk a launch takes: 0 = launch_trunk_f16x3's own rule; 1 = register-resident with room beside it
     // (ring of 3); 2 = weight-stationary.  Set by forward_tiles_split around its two trunk launches.
     int trunk_force = 0;
+    bool em_beside = false;  // the prologue being launched runs beside a trunk of this call (forward_tiles_split): shallow weight ring
     int64_t split_min = 3200;  // MSIREN_SPLIT_MIN: *_dev forward calls of at least this many tiles are cut in two (0 = never)
     int split_pct = 12;        // MSIREN_SPLIT_PCT: share of the first part, percent
     int lin_tile_min = 1024;   // MSIREN_LINEAR_TILE_MIN: rows from which the Linear layers use the 32 x 32-tile kernel (0 = never)
@@ -138,6 +142,15 @@ struct msiren_ctx {
     // encoder
     float *d_encw = nullptr, *d_c3w_rm = nullptr, *d_fcw_rm = nullptr;  // the latter two point into d_encw
     msiren::EncoderParams enc{};
+    // encoder tail + Modulator in split-fp16 arithmetic, one launch (encoder_modulator_f16x3.hip.h); every precision but fp32
+    void* d_emw = nullptr;         // packed weight streams of the four waves
+    float* d_embias = nullptr;     // [conv3 64][fc Z][modulator L x H]
+    float em_winv_c3 = 1.f, em_winv_fc = 1.f, em_winv_z[64] = {0}, em_winv_h[64] = {0};
+    int em_wave_stride = 0, em_zp_start = 0;
+    bool em_enc = false, em_mod = false;  // which halves of the stream are packed (the checkpoint's key set decides)
+    int em_depth = 0;              // MSIREN_EM_DEPTH=2|4|8: force the weight-ring depth of the split-fp16 prologue (A/B knob)
+    int ws_two = 0;                // MSIREN_WS_TWO=1: the weight-stationary trunk on two-stream handles as well (experiment)
+    int em_enabled = 1;            // MSIREN_PROLOGUE_F16X3=0: the exact-fp32 launches per layer (A/B knob, read at create)
     float* d_foldw = nullptr;  // (S,S) overlap-add weights
     // workspaces
     DevBuf ws_out, ws_tiles, ws_in, ws_img;  // staging of the host-pointer entry points
@@ -567,6 +580,116 @@ int pack_encoder(msiren_ctx* h) {
     return 0;
 }
 
+// ---- encoder tail + Modulator, split-fp16 (encoder_modulator_f16x3.hip.h) ------------------------------------------------
+// Per wave one stream of k-steps in the order the kernel consumes them, each [tile 0 hi | tile 0 lo | tile 1 hi | tile 1 lo]
+// x [64 lanes][8 x f16]; lane (m = lane & 15, q = lane >> 4), element j: output feature 16 T + m, input
+// k(s, q, j) = 32 s + 16 (j >> 2) + 4 q + (j & 3) of k-step s.  Sections: conv3 (32 k-steps: the wave's K half of its tile
+// pair), Linear(64, Z) (NPZ passes x 4 k-steps, the upper two zero), the latent part of every Modulator layer (L NPH passes
+// x Z / 32), the hidden part of layers 1.. ((L - 1) NPH passes x H / 32).  Each layer is scaled by the power of two that
+// brings max|W| into [2^13, 2^14) before the hi / lo split.
+int pack_prologue_f16x3(msiren_ctx* h) {
+    h->em_enc = h->em_mod = false;
+    const int H = h->H, Z = h->Z, L = h->L;
+    const bool enc = h->have_encoder && h->O == 32, mod = h->have_modulator;  // (a trunk + Modulator checkpoint has no encoder.* keys)
+    if (!h->em_enabled || h->cfg.precision == MSIREN_PREC_F32 || (!enc && !mod)) return 0;
+    if (!((H == 256 && Z == 256) || (H == 512 && Z == 128)) || L > 64) return 0;  // the instantiated (NPH, NPZ) pairs
+    const int NPH = H / 128, NPZ = Z / 128, KH = H / 32, KZ = Z / 32;
+    auto scale_of = [](const float* w, size_t n0, size_t stride, size_t rows, size_t cols) {  // exponent a: max|w| 2^a in [2^13, 2^14)
+        double mx = 0.0;
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t c = 0; c < cols; ++c) mx = std::max(mx, std::fabs((double)w[n0 + r * stride + c]));
+        if (!(mx > 0.0) || !std::isfinite(mx)) return 0;
+        int e = 0;
+        (void)std::frexp(mx, &e);  // mx = f 2^e, f in [0.5, 1)
+        return std::max(-100, std::min(100, 14 - e));
+    };
+    const int zp_start = enc ? msiren::EM_C3_KSTEPS / 2 + NPZ * msiren::EM_FC_KSTEPS : 0;
+    const int nk = zp_start + (mod ? L * NPH * KZ + (L - 1) * NPH * KH : 0);
+    std::vector<uint16_t> ws(((size_t)4 * nk + msiren::EM_MAX_DEPTH) * 4 * 64 * 8, 0);  // (+ padding: the ring prefetches past the end)
+    auto put = [&](int wave, int g, int t, int lane, int j, double v) {  // v already scaled
+        const float f = (float)v;
+        const uint16_t hi = f32_to_f16_rne(f), lo = f32_to_f16_rne(f - f16_to_f32(hi));
+        const size_t base = (((size_t)wave * nk + g) * 4 + 2 * t) * 64 * 8 + (size_t)lane * 8 + j;
+        ws[base] = hi;
+        ws[base + 64 * 8] = lo;
+    };
+    auto kin = [](int s, int q, int j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); };
+    std::vector<float> bias((size_t)64 + Z + (size_t)L * H, 0.f);
+    if (enc) {
+    const std::string en = "encoder.encoder.encoder.";
+    const std::vector<float>&W3 = *get(h, en + "4.weight"), &B3 = *get(h, en + "4.bias"), &Wf = *get(h, en + "7.weight"), &Bf = *get(h, en + "7.bias");
+    // conv3: k-step s of the conv kernel's images holds, for q and j, channel 8 (s >> 4) + j at position 4 (s & 15) + q
+    const int a3 = scale_of(W3.data(), 0, 2048, 64, 2048);
+    h->em_winv_c3 = (float)std::ldexp(1.0, -a3);
+    for (int wave = 0; wave < 4; ++wave)
+        for (int ks = 0; ks < msiren::EM_C3_KSTEPS / 2; ++ks)
+            for (int t = 0; t < 2; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int s2 = (msiren::EM_C3_KSTEPS / 2) * (wave >> 1) + ks, f = 32 * (wave & 1) + 16 * t + (lane & 15);
+                        const int k = (8 * (s2 >> 4) + j) * 64 + 4 * (s2 & 15) + (lane >> 4);
+                        put(wave, ks, t, lane, j, std::ldexp((double)W3[(size_t)f * 2048 + k], a3));
+                    }
+    for (int f = 0; f < 64; ++f) bias[f] = B3[f];
+    const int af = scale_of(Wf.data(), 0, 64, Z, 64);
+    h->em_winv_fc = (float)std::ldexp(1.0, -af);
+    for (int wave = 0; wave < 4; ++wave)
+        for (int pz = 0; pz < NPZ; ++pz)
+            for (int ks = 0; ks < 2; ++ks)  // (k-steps 2, 3 of a pass stay zero)
+                for (int t = 0; t < 2; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int f = 128 * pz + 32 * wave + 16 * t + (lane & 15);
+                            put(wave, msiren::EM_C3_KSTEPS / 2 + pz * msiren::EM_FC_KSTEPS + ks, t, lane, j,
+                                std::ldexp((double)Wf[(size_t)f * 64 + kin(ks, lane >> 4, j)], af));
+                        }
+    for (int f = 0; f < Z; ++f) bias[64 + f] = Bf[f];
+    }
+    for (int l = 0; l < L && mod; ++l) {
+        const std::vector<float>& W = *get(h, "modulator.layers." + std::to_string(l) + ".0.weight");
+        const std::vector<float>& Bm = *get(h, "modulator.layers." + std::to_string(l) + ".0.bias");
+        const int Kh = l == 0 ? 0 : H, K = Kh + Z;
+        const int az = scale_of(W.data(), (size_t)Kh, (size_t)K, H, Z);
+        h->em_winv_z[l] = (float)std::ldexp(1.0, -az);
+        for (int wave = 0; wave < 4; ++wave)
+            for (int ph = 0; ph < NPH; ++ph)
+                for (int ks = 0; ks < KZ; ++ks)
+                    for (int t = 0; t < 2; ++t)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int f = 128 * ph + 32 * wave + 16 * t + (lane & 15);
+                                put(wave, zp_start + (l * NPH + ph) * KZ + ks, t, lane, j,
+                                    std::ldexp((double)W[(size_t)f * K + Kh + kin(ks, lane >> 4, j)], az));
+                            }
+        if (l > 0) {
+            const int ah = scale_of(W.data(), 0, (size_t)K, H, H);
+            h->em_winv_h[l] = (float)std::ldexp(1.0, -ah);
+            for (int wave = 0; wave < 4; ++wave)
+                for (int ph = 0; ph < NPH; ++ph)
+                    for (int ks = 0; ks < KH; ++ks)
+                        for (int t = 0; t < 2; ++t)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int f = 128 * ph + 32 * wave + 16 * t + (lane & 15);
+                                    put(wave, zp_start + L * NPH * KZ + ((l - 1) * NPH + ph) * KH + ks, t, lane, j,
+                                        std::ldexp((double)W[(size_t)f * K + kin(ks, lane >> 4, j)], ah));
+                                }
+        }
+        for (int f = 0; f < H; ++f) bias[(size_t)64 + Z + (size_t)l * H + f] = Bm[f];
+    }
+    if (h->d_emw) HIPCHK(hipFree(h->d_emw));
+    h->d_emw = nullptr;
+    HIPCHK(hipMalloc(&h->d_emw, ws.size() * 2));
+    HIPCHK(hipMemcpy(h->d_emw, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = upload(&h->d_embias, bias))) return rc;
+    h->em_wave_stride = nk * 256;
+    h->em_zp_start = zp_start;
+    h->em_enc = enc;
+    h->em_mod = mod;
+    return 0;
+}
+
 int pack_fold_weights(msiren_ctx* h) {
     // w[i][j] = exp(-0.1 * dist((i,j), centre)) / max   (src/util/tiling.py:67-88; fp64 maths
     // rounded to fp32 element-wise, then divided by the fp32 maximum, as the reference does)
@@ -765,7 +888,7 @@ bool ws_capable(msiren_ctx* h, int64_t B) {
     static_assert(msiren::WsLds<4>::total(msiren::WS_MAX_L) <= 160 * 1024, "unit images + tables of the deepest supported model must fit the LDS");
     return h->f16_ws && h->L >= msiren::WS_MIN_L && h->L <= msiren::WS_MAX_L && (int64_t)h->L * B * 256 * 4 < (1LL << 32);
 }
-bool use_f16x3w(msiren_ctx* h, int64_t B) { return ws_capable(h, B) && (h->nstreams == 1 || h->solo) && !h->overlap; }
+bool use_f16x3w(msiren_ctx* h, int64_t B) { return ws_capable(h, B) && (h->nstreams == 1 || h->solo || h->ws_two) && !h->overlap; }
 
 int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     const int upp_ = (h->P + 31) / 32;
@@ -1044,9 +1167,72 @@ int launch_linear(msiren_ctx* h, const msiren::ModulatorMfmaParams& mp) {
     return 0;
 }
 
+// encoder tail + Modulator in ONE launch (plus the conv kernel in front when tiles are given): split-fp16 arithmetic,
+// a row block of 16 patches per workgroup through every layer (encoder_modulator_f16x3.hip.h).
+//   tiles -> [z_out] -> [mods]     (tiles_dev given)        z_in -> mods     (tiles_dev null)
+template <int NPH, int NPZ>
+int launch_prologue_f16x3_t(msiren_ctx* h, const float* tiles_dev, const float* z_in, int64_t B, float* z_out, float* mods_dev) {
+    auto& c = h->sc[h->cur];
+    const int64_t nblk = (B + msiren::EM_ROWS - 1) / msiren::EM_ROWS, rows16 = nblk * msiren::EM_ROWS;
+    if (nblk > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
+    int rc;
+    msiren::EmTailParams p{};
+    if (tiles_dev) {
+        if ((rc = ensure(h, c.feat, (size_t)rows16 * 2048 * 4 + (size_t)rows16 * 4 + msiren::EM_MAX_DEPTH * 2048))) return rc;  // (+ padding: conv3's B ring prefetches past the end)
+        p.feat = (const msiren::em_u4*)c.feat.p;
+        p.feat_inv = (const float*)((const char*)c.feat.p + (size_t)rows16 * 2048 * 4 + msiren::EM_MAX_DEPTH * 2048);
+        h->enc.plan = h->plan;
+        hipLaunchKernelGGL(msiren::encoder_conv_f16x3_kernel<0>, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, (msiren::em_u4*)c.feat.p,
+                           (float*)((char*)c.feat.p + (size_t)rows16 * 2048 * 4 + msiren::EM_MAX_DEPTH * 2048));
+        HIPCHK(hipGetLastError());
+    }
+    if (mods_dev) {
+        if ((rc = ensure(h, c.cscratch, (size_t)nblk * std::max(1, h->L - 1) * NPH * 512 * 16))) return rc;
+        p.cscratch = (msiren::em_f4*)c.cscratch.p;
+    }
+    p.wstream = (const msiren::em_u4*)h->d_emw;
+    p.bias = h->d_embias;
+    p.z_in = z_in;
+    p.z_out = z_out;
+    p.mods = mods_dev;
+    p.winv_c3 = h->em_winv_c3;
+    p.winv_fc = h->em_winv_fc;
+    for (int l = 0; l < 64; ++l) {
+        p.winv_z[l] = h->em_winv_z[l];
+        p.winv_h[l] = h->em_winv_h[l];
+    }
+    p.B = (int)B;
+    p.L = h->L;
+    p.wave_stride = h->em_wave_stride;
+    p.zp_start = h->em_zp_start;
+    p.count = h->plan;
+    const int lds = msiren::em_tail_lds_bytes<NPH, NPZ>();
+    // ring depth 4 (more weight fragments in flight per wave) where the workgroups have their CUs to themselves; depth 2 (<= 96
+    // registers, 33 KB of LDS) where they run beside the register-resident trunk of the other stream or many to a CU.  Same bits.
+    const bool alone = (h->nstreams == 1 || h->solo) && !h->overlap && h->trunk_force == 0 && !h->em_beside;
+    int depth = alone ? (nblk <= (int64_t)h->num_cus ? 8 : 4) : 2;
+    if (h->em_depth) depth = h->em_depth;
+    if constexpr (NPH > 2) {
+        hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 4>), dim3((unsigned)nblk), dim3(256), lds, c.s, p);
+    } else {
+        if (depth >= 8) hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 8>), dim3((unsigned)nblk), dim3(256), lds, c.s, p);
+        else if (depth >= 4) hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 4>), dim3((unsigned)nblk), dim3(256), lds, c.s, p);
+        else hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 2>), dim3((unsigned)nblk), dim3(256), lds, c.s, p);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_prologue_f16x3(msiren_ctx* h, const float* tiles_dev, const float* z_in, int64_t B, float* z_out, float* mods_dev) {
+    if (B == 0) return 0;
+    if (h->H == 256) return launch_prologue_f16x3_t<2, 2>(h, tiles_dev, z_in, B, z_out, mods_dev);
+    return launch_prologue_f16x3_t<4, 1>(h, tiles_dev, z_in, B, z_out, mods_dev);
+}
+
 int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_dev) {
     if (B == 0) return 0;
     if (!h->have_modulator) return fail(MSIREN_E_STATE, "modulator.* weights were not loaded");
+    if (h->em_mod) return launch_prologue_f16x3(h, nullptr, z_dev, B, nullptr, mods_dev);
     size_t off = 0;
     const bool mfma_ok = (h->H % 16 == 0) && (h->Z % 16 == 0);
     for (int l = 0; l < h->L && mfma_ok; ++l) {
@@ -1094,6 +1280,7 @@ int launch_modulator(msiren_ctx* h, const float* z_dev, int64_t B, float* mods_d
 int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_dev) {
     if (B == 0) return 0;
     if (!h->have_encoder) return fail(MSIREN_E_STATE, "encoder.* weights were not loaded");
+    if (h->em_enc) return launch_prologue_f16x3(h, tiles_dev, nullptr, B, z_dev, nullptr);
     hipStream_t s = h->sc[h->cur].s;
     h->enc.plan = h->plan;
     // small batches are launch-latency bound: one fused per-tile kernel instead of three launches
@@ -1134,6 +1321,7 @@ int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_de
 // encoder + modulator: tiles -> latent -> modulations
 int launch_encoder_modulator(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_dev, float* mods_dev) {
     if (B == 0) return 0;
+    if (h->em_enc && h->em_mod) return launch_prologue_f16x3(h, tiles_dev, nullptr, B, nullptr, mods_dev);  // (the latent stays in the workgroup)
     int rc = launch_encoder(h, tiles_dev, B, z_dev);
     if (rc) return rc;
     return launch_modulator(h, z_dev, B, mods_dev);
@@ -1189,7 +1377,10 @@ int forward_tiles_split(msiren_ctx* h, const float* tiles_dev, int64_t B, float*
     HIPCHK(hipEventRecord(A.ev_fork, A.s));
     HIPCHK(hipStreamWaitEvent(O.s, A.ev_fork, 0));
     h->cur = b;  // part 1's prologue first: it is the long one, and nothing it needs is still to come
-    if ((rc = launch_encoder_modulator(h, tiles_dev + (size_t)B0 * h->O * h->O, B1, (float*)O.latent.p, (float*)A.mods2.p))) return rc;
+    h->em_beside = true;
+    rc = launch_encoder_modulator(h, tiles_dev + (size_t)B0 * h->O * h->O, B1, (float*)O.latent.p, (float*)A.mods2.p);
+    h->em_beside = false;
+    if (rc) return rc;
     HIPCHK(hipEventRecord(A.ev_join, O.s));
     h->cur = a;
     if ((rc = launch_encoder_modulator(h, tiles_dev, B0, (float*)A.latent.p, (float*)A.mods.p))) return rc;
@@ -1420,6 +1611,9 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_LINEAR_TILE_MIN")) { h->lin_tile_min = std::max(0, std::atoi(e)); h->lin_tile_env = true; }
     if (const char* e = std::getenv("MSIREN_SPLIT_PCT")) h->split_pct = std::max(1, std::min(90, std::atoi(e)));
     if (const char* e = std::getenv("MSIREN_TRACE_HOST")) h->trace_host = std::atoi(e);
+    if (const char* e = std::getenv("MSIREN_PROLOGUE_F16X3")) h->em_enabled = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_EM_DEPTH")) h->em_depth = std::atoi(e);
+    if (const char* e = std::getenv("MSIREN_WS_TWO")) h->ws_two = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_HOST_SPLIT")) h->host_first_pct = std::max(5, std::min(95, std::atoi(e)));
     declare_expected(h);
     hipError_t e = hipSetDevice(cfg->device);
@@ -1450,12 +1644,13 @@ int msiren_destroy(msiren_handle h) {
     if (h->status_host) (void)hipHostFree((void*)h->status_host);
     if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
     if (h->d_wp16n) (void)hipFree(h->d_wp16n);
+    if (h->d_emw) (void)hipFree(h->d_emw);
     for (void* q : {h->d_woutx1, h->d_wpx1n, h->d_wpx1w, (void*)h->d_bias32x1})
         if (q) (void)hipFree(q);
-    float* ptrs[] = {h->d_dump, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw};
+    float* ptrs[] = {h->d_dump, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw, h->d_embias};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
-    DevBuf* bufs[] = {&h->sc[0].mods2, &h->sc[1].mods2, &h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
+    DevBuf* bufs[] = {&h->sc[0].cscratch, &h->sc[1].cscratch, &h->sc[0].mods2, &h->sc[1].mods2, &h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
                       &h->sc[0].patches, &h->sc[0].keep, &h->sc[0].rec, &h->sc[1].mods, &h->sc[1].modpad, &h->sc[1].latent,
                       &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec, &h->sc[0].queue, &h->sc[1].queue, &h->sc[0].feat, &h->sc[1].feat, &h->sc[0].plan, &h->sc[1].plan};
     for (DevBuf* b : bufs)
@@ -1512,6 +1707,7 @@ int msiren_commit_weights(msiren_handle h) {
     rc = pack_encoder(h);
     if (rc < 0) return rc;
     h->have_encoder = (rc == 0);
+    if ((rc = pack_prologue_f16x3(h))) return rc;
     h->committed = true;
     return 0;
 }

@@ -276,20 +276,25 @@ def test_no_vector_memory_instruction_of_the_built_library_reads_a_freshly_valu_
     if not (os.path.exists(objdump) and os.path.exists(lib)):
         pytest.skip("needs the built library and llvm-objdump")
     blob = open(lib, "rb").read()
-    at = blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    # one offload bundle per translation unit (msiren.hip and the k_*.hip kernel units): every gfx950 code object is scanned
+    text, at, nobj = "", blob.find(b"__CLANG_OFFLOAD_BUNDLE__"), 0
     assert at >= 0
-    (n,), pos, elf = struct.unpack_from("<Q", blob, at + 24), at + 32, None
-    for _ in range(n):
-        off, size, tl = struct.unpack_from("<QQQ", blob, pos)
-        triple = blob[pos + 24:pos + 24 + tl].decode()
-        pos += 24 + tl
-        if "gfx950" in triple:
-            elf = blob[at + off:at + off + size]
-    assert elf, "no gfx950 code object in the library"
-    co = tmp_path / "co.elf"
-    co.write_bytes(elf)
-    res = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
+    while at >= 0:
+        (n,), pos = struct.unpack_from("<Q", blob, at + 24), at + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, pos)
+            triple = blob[pos + 24:pos + 24 + tl].decode()
+            pos += 24 + tl
+            if "gfx950" in triple and size:
+                co = tmp_path / f"co{nobj}.elf"
+                co.write_bytes(blob[at + off:at + off + size])
+                res = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True, timeout=600)
+                assert res.returncode == 0, res.stderr[-2000:]
+                text += "\n" + res.stdout
+                nobj += 1
+        at = blob.find(b"__CLANG_OFFLOAD_BUNDLE__", at + 24)
+    assert nobj >= 1, "no gfx950 code object in the library"
+    res = type("R", (), {"stdout": text})
     kernels = re.split(r"\n(?=[0-9a-f]{16} <[^>]+>:\n)", res.stdout)[1:]
     assert len(kernels) >= 50, len(kernels)
     total, names = 0, []

@@ -4,7 +4,7 @@
 # with other trace domains); FETCH_SIZE and WRITE_SIZE need separate passes (TCC slot budget).
 set -u
 OUT=${1:-gpurun_out/prof}; shift || true
-ARGS=${@:---steps 10 --warmup 3 --no-cpu-baseline}
+ARGS=${@:---steps 10 --warmup 3 --no-cpu-baseline --no-extras}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 run() { name=$1; shift; timeout -k 10 300 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1 || echo "pass $name failed"; }
