@@ -401,70 +401,166 @@ template <int NPH, int NPZ>
 constexpr int em_tail_lds_bytes() { return (128 * NPZ * 4 + 128 * NPH * 4) * 16 + 256; }
 
 // ---- conv1 + conv2 of the encoder, writing conv3's B images --------------------------------------------------------------
-// encoder_conv_kernel's arithmetic (fp32 FMAs in the same order: the same feature values), another epilogue: the tile's 2048
-// features are scaled by the row's power of two, split, and stored as this row's column of the row block's 64 k-step images.
-// k order of conv3 as this kernel produces it: thread (wave wv, position pos) holds channels 8 wv + j at pos, so
-// k-step s = 16 wv + (pos >> 2), q = pos & 3, element j  <->  torch's flattened index (8 wv + j) * 64 + pos.
-template <int VARIANT>  // 0: conv2 on the VALU (encoder_conv_kernel's loop)
+// One workgroup per 32 x 32 tile.  The tile's 2048 conv2 features are scaled by the row's power of two, split, and stored as
+// this row's column of the row block's 64 k-step images; thread (wave w, lane) stores the 16-byte piece (k-step 16 w + (lane >> 2),
+// q = lane & 3), so conv3's k order is whatever values the thread holds (the host packs conv3's weights to match, per variant).
+//
+// VARIANT 0: conv2 on the VALU, encoder_conv_kernel's loop (fp32 FMAs in the same order: the same feature values before the
+//   split).  Thread (w, pos) holds channels 8 w + j at position pos.
+// VARIANT 1: conv2 as an implicit GEMM on the matrix cores in the split-fp16 arithmetic.  conv1 (K = 9: VALU, one thread per
+//   output position, all 16 channels, fp32 FMAs in the reference order) leaves its output in LDS as conv2's B operand:
+//   [padded position 17 x 17][hi: 16 channels | lo: 16 channels] x f16, scaled by the tile's own power of two.  A k-step is two
+//   taps x 16 channels (9 taps -> 5 k-steps, the tenth tap has zero weights), so a lane's eight B elements are eight consecutive
+//   channels of one position: one ds_read_b128.  Wave w = (channel tile w & 1, position tiles 2 (w >> 1) + {0, 1}); the
+//   weights of its channel tile sit in 40 registers, fetched while conv1 runs.  Thread (w, lane (n, q)) ends up with channels
+//   16 (w & 1) + 4 q + r at positions 16 (2 (w >> 1) + t) + n  (j = 4 t + r).
+template <int VARIANT>
 __global__ __launch_bounds__(256, 5) void encoder_conv_f16x3_kernel(EncoderParams p, const float* __restrict__ tiles, em_u4* __restrict__ feat,
                                                                       float* __restrict__ feat_inv) {
-    constexpr int RSP = 12, PLANE = 17 * RSP;
     __shared__ float t0[33 * 33];
-    __shared__ float a1[16 * 2 * PLANE];
-    __shared__ float wmax[4];
+    __shared__ float wmax[8];
     const int tid = threadIdx.x;
     if (p.plan && (int)blockIdx.x >= p.plan[0]) return;  // workgroup-uniform
     const float* tile = tiles + (size_t)(p.plan ? p.plan[2 + blockIdx.x] : (int)blockIdx.x) * 1024;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    em_f4 o0, o1;  // the thread's eight features (before scale and split)
 
-    for (int i = tid; i < 33 * 33; i += 256) {
-        const int y = i / 33, x = i - y * 33;
-        t0[i] = (y == 0 || x == 0) ? 0.f : tile[(y - 1) * 32 + (x - 1)];
-    }
-    for (int i = tid; i < 16 * 2 * PLANE; i += 256) a1[i] = 0.f;
-    __syncthreads();
-    for (int i = tid; i < 16 * 256; i += 256) {
-        const int c = i >> 8, y = (i >> 4) & 15, x = i & 15;
-        float s = p.c1b[c];
+    if constexpr (VARIANT == 0) {
+        constexpr int RSP = 12, PLANE = 17 * RSP;
+        __shared__ float a1[16 * 2 * PLANE];
+        for (int i = tid; i < 33 * 33; i += 256) {
+            const int y = i / 33, x = i - y * 33;
+            t0[i] = (y == 0 || x == 0) ? 0.f : tile[(y - 1) * 32 + (x - 1)];
+        }
+        for (int i = tid; i < 16 * 2 * PLANE; i += 256) a1[i] = 0.f;
+        __syncthreads();
+        for (int i = tid; i < 16 * 256; i += 256) {
+            const int c = i >> 8, y = (i >> 4) & 15, x = i & 15;
+            float s = p.c1b[c];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) s = __builtin_fmaf(t0[(2 * y + ky) * 33 + 2 * x + kx], p.c1w[c * 9 + ky * 3 + kx], s);
-        const int col = x + 1;
-        a1[(c * 2 + (col & 1)) * PLANE + (y + 1) * RSP + (col >> 1)] = leaky02(s);
-    }
-    __syncthreads();
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, y = lane >> 3, x = lane & 7;
-    float s[8];
+                for (int kx = 0; kx < 3; ++kx) s = __builtin_fmaf(t0[(2 * y + ky) * 33 + 2 * x + kx], p.c1w[c * 9 + ky * 3 + kx], s);
+            const int col = x + 1;
+            a1[(c * 2 + (col & 1)) * PLANE + (y + 1) * RSP + (col >> 1)] = leaky02(s);
+        }
+        __syncthreads();
+        const int y = lane >> 3, x = lane & 7;
+        float s[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = p.c2b[8 * wv + j];
-    for (int c = 0; c < 16; ++c)
+        for (int j = 0; j < 8; ++j) s[j] = p.c2b[8 * wv + j];
+        for (int c = 0; c < 16; ++c)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const float* even = &a1[(c * 2 + 0) * PLANE + (2 * y + ky) * RSP + x];
-            const float* odd = &a1[(c * 2 + 1) * PLANE + (2 * y + ky) * RSP + x];
-            const float in[3] = {even[0], odd[0], even[1]};
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* even = &a1[(c * 2 + 0) * PLANE + (2 * y + ky) * RSP + x];
+                const float* odd = &a1[(c * 2 + 1) * PLANE + (2 * y + ky) * RSP + x];
+                const float in[3] = {even[0], odd[0], even[1]};
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const float* w = p.c2w + (c * 9 + ky * 3 + kx) * 32 + 8 * wv;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float* w = p.c2w + (c * 9 + ky * 3 + kx) * 32 + 8 * wv;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] = __builtin_fmaf(in[kx], w[j], s[j]);
+                    for (int j = 0; j < 8; ++j) s[j] = __builtin_fmaf(in[kx], w[j], s[j]);
+                }
+            }
+        o0 = em_f4{leaky02(s[0]), leaky02(s[1]), leaky02(s[2]), leaky02(s[3])};
+        o1 = em_f4{leaky02(s[4]), leaky02(s[5]), leaky02(s[6]), leaky02(s[7])};
+    } else {
+        __shared__ __attribute__((aligned(16))) em_u4 a1img[17 * 17 * 4];  // [position][hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]
+        const int n = lane & 15, q = lane >> 4, mt = wv & 1;
+        // conv2's weights of this wave's channel tile: in flight while conv1 runs
+        em_u4 wa[5][2];
+        {
+            const em_u4* wsrc = reinterpret_cast<const em_u4*>(p.c2f16) + (size_t)mt * 5 * 2 * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                wa[s][0] = wsrc[(s * 2 + 0) * 64];
+                wa[s][1] = wsrc[(s * 2 + 1) * 64];
             }
         }
-    float m = 0.f;
+        const em_f4 b2 = *reinterpret_cast<const em_f4*>(p.c2b + 16 * mt + 4 * q);
+        for (int i = tid; i < 33 * 33; i += 256) {
+            const int y = i / 33, x = i - y * 33;
+            t0[i] = (y == 0 || x == 0) ? 0.f : tile[(y - 1) * 32 + (x - 1)];
+        }
+        if (tid < 33) {  // the front padding of conv1's output: row 0 and column 0
+            const int pos = tid < 17 ? tid : (tid - 16) * 17;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        s[j] = leaky02(s[j]);
-        m = __builtin_fmaxf(m, __builtin_fabsf(s[j]));
+            for (int i = 0; i < 4; ++i) a1img[pos * 4 + i] = em_u4{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();
+        // conv1: thread = output position (y, x) of the 16 x 16 map, all 16 channels
+        float a[16];
+        {
+            const int y = tid >> 4, x = tid & 15;
+            float in[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) in[ky * 3 + kx] = t0[(2 * y + ky) * 33 + 2 * x + kx];
+            float m = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float s = p.c1b[c];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) s = __builtin_fmaf(in[k], p.c1w[c * 9 + k], s);
+                a[c] = leaky02(s);
+                m = __builtin_fmaxf(m, __builtin_fabsf(a[c]));
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d));
+            if (lane == 0) wmax[wv] = m;
+        }
+        __syncthreads();
+        float inv1;
+        {
+            const float m = __builtin_fmaxf(__builtin_fmaxf(wmax[0], wmax[1]), __builtin_fmaxf(wmax[2], wmax[3]));
+            float sc1;
+            em_row_scale(m, sc1, inv1);
+            const int y = tid >> 4, x = tid & 15;
+            em_u4 h0, l0, h1, l1;
+            em_split8(em_f4{a[0] * sc1, a[1] * sc1, a[2] * sc1, a[3] * sc1}, em_f4{a[4] * sc1, a[5] * sc1, a[6] * sc1, a[7] * sc1}, h0, l0);
+            em_split8(em_f4{a[8] * sc1, a[9] * sc1, a[10] * sc1, a[11] * sc1}, em_f4{a[12] * sc1, a[13] * sc1, a[14] * sc1, a[15] * sc1}, h1, l1);
+            em_u4* dst = a1img + ((y + 1) * 17 + (x + 1)) * 4;
+            dst[0] = h0;
+            dst[1] = h1;
+            dst[2] = l0;
+            dst[3] = l1;
+        }
+        __syncthreads();
+        // conv2: [16 channels of tile mt] x [2 x 16 positions], K = 5 k-steps of (2 taps x 16 channels)
+        em_f4 acc[2] = {em_f4{0.f, 0.f, 0.f, 0.f}, em_f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            int tap = 2 * s + (q >> 1);
+            tap = tap > 8 ? 8 : tap;  // (the tenth tap: zero weights, any finite operand)
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int pos = 16 * (2 * (wv >> 1) + t) + n, y = pos >> 3, x = pos & 7;
+                const em_u4* src = a1img + ((2 * y + ky) * 17 + 2 * x + kx) * 4 + (q & 1);
+                const em_u4 bh = src[0], bl = src[2];
+                acc[t] = em_mfma(wa[s][1], bh, acc[t]);
+                acc[t] = em_mfma(wa[s][0], bl, acc[t]);
+                acc[t] = em_mfma(wa[s][0], bh, acc[t]);
+            }
+        }
+        const float u = inv1 * p.c2_winv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o0[r] = leaky02(__builtin_fmaf(acc[0][r], u, b2[r]));
+            o1[r] = leaky02(__builtin_fmaf(acc[1][r], u, b2[r]));
+        }
     }
+    float m = em_absmax8(o0, o1);
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d));
-    if (lane == 0) wmax[wv] = m;
+    if (lane == 0) wmax[4 + wv] = m;
     __syncthreads();
-    m = __builtin_fmaxf(__builtin_fmaxf(wmax[0], wmax[1]), __builtin_fmaxf(wmax[2], wmax[3]));
+    m = __builtin_fmaxf(__builtin_fmaxf(wmax[4], wmax[5]), __builtin_fmaxf(wmax[6], wmax[7]));
     float sc, inv;
     em_row_scale(m, sc, inv);
     em_u4 hi, lo;
-    em_split8(em_f4{s[0] * sc, s[1] * sc, s[2] * sc, s[3] * sc}, em_f4{s[4] * sc, s[5] * sc, s[6] * sc, s[7] * sc}, hi, lo);
+    em_split8(o0 * sc, o1 * sc, hi, lo);
     const int row = blockIdx.x, ks = 16 * wv + (lane >> 2), qq = lane & 3;
     em_u4* dst = feat + ((size_t)(row >> 4) * EM_C3_KSTEPS + ks) * 128 + qq * 16 + (row & 15);
     dst[0] = hi;

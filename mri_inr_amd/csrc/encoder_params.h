@@ -15,6 +15,8 @@ struct EncoderParams {
     const float* fcw;  // (64, Z) transposed   Linear(64, Z)
     const float* fcb;  // (Z)
     int Z;
+    const void* c2f16;  // conv2 as MFMA A fragments, split fp16: [2 channel tiles][5 k-steps][hi|lo][64 lanes][8 x f16] (encoder_modulator_f16x3.hip.h)
+    float c2_winv;      // exact inverse of conv2's power-of-two weight scale
     const int* plan;   // optional (compact_flags_kernel): workgroup j handles tile plan[2 + j], j < plan[0]
 };
 

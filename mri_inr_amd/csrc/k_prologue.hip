@@ -6,4 +6,5 @@ template __global__ void latent_mods_f16x3_kernel<2, 2, 4>(EmTailParams);
 template __global__ void latent_mods_f16x3_kernel<2, 2, 8>(EmTailParams);
 template __global__ void latent_mods_f16x3_kernel<4, 1, 4>(EmTailParams);
 template __global__ void encoder_conv_f16x3_kernel<0>(EncoderParams, const float*, em_u4*, float*);
+template __global__ void encoder_conv_f16x3_kernel<1>(EncoderParams, const float*, em_u4*, float*);
 }  // namespace msiren

@@ -144,6 +144,8 @@ struct msiren_ctx {
     msiren::EncoderParams enc{};
     // encoder tail + Modulator in split-fp16 arithmetic, one launch (encoder_modulator_f16x3.hip.h); every precision but fp32
     void* d_emw = nullptr;         // packed weight streams of the four waves
+    void* d_emc2 = nullptr;        // conv2's MFMA A fragments
+    int em_conv_mfma = 1;          // MSIREN_CONV_MFMA=0: conv2 on the VALU (A/B knob, read at create)
     float* d_embias = nullptr;     // [conv3 64][fc Z][modulator L x H]
     float em_winv_c3 = 1.f, em_winv_fc = 1.f, em_winv_z[64] = {0}, em_winv_h[64] = {0};
     int em_wave_stride = 0, em_zp_start = 0;
@@ -618,7 +620,30 @@ int pack_prologue_f16x3(msiren_ctx* h) {
     if (enc) {
     const std::string en = "encoder.encoder.encoder.";
     const std::vector<float>&W3 = *get(h, en + "4.weight"), &B3 = *get(h, en + "4.bias"), &Wf = *get(h, en + "7.weight"), &Bf = *get(h, en + "7.bias");
-    // conv3: k-step s of the conv kernel's images holds, for q and j, channel 8 (s >> 4) + j at position 4 (s & 15) + q
+    // conv2 as MFMA A fragments: lane (m, q), element j of k-step s: channel 16 mt + m, tap 2 s + (q >> 1), input channel 8 (q & 1) + j
+    {
+        const std::vector<float>& W2 = *get(h, en + "2.weight");  // (32, 16, 3, 3)
+        const int a2 = scale_of(W2.data(), 0, 144, 32, 144);
+        std::vector<uint16_t> c2((size_t)2 * 5 * 2 * 64 * 8, 0);
+        for (int mt = 0; mt < 2; ++mt)
+            for (int ks = 0; ks < 5; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int tap = 2 * ks + (lane >> 5), ci = 8 * ((lane >> 4) & 1) + j, o = 16 * mt + (lane & 15);
+                        const float f = tap < 9 ? (float)std::ldexp((double)W2[(size_t)o * 144 + ci * 9 + tap], a2) : 0.f;
+                        const uint16_t hi = f32_to_f16_rne(f), lo = f32_to_f16_rne(f - f16_to_f32(hi));
+                        const size_t base = ((size_t)(mt * 5 + ks) * 2) * 64 * 8 + (size_t)lane * 8 + j;
+                        c2[base] = hi;
+                        c2[base + 64 * 8] = lo;
+                    }
+        if (h->d_emc2) HIPCHK(hipFree(h->d_emc2));
+        h->d_emc2 = nullptr;
+        HIPCHK(hipMalloc(&h->d_emc2, c2.size() * 2));
+        HIPCHK(hipMemcpy(h->d_emc2, c2.data(), c2.size() * 2, hipMemcpyHostToDevice));
+        h->enc.c2f16 = h->d_emc2;
+        h->enc.c2_winv = (float)std::ldexp(1.0, -a2);
+    }
+    // conv3: its k order is the order in which the conv kernel's threads hold the features (encoder_conv_f16x3_kernel<VARIANT>)
     const int a3 = scale_of(W3.data(), 0, 2048, 64, 2048);
     h->em_winv_c3 = (float)std::ldexp(1.0, -a3);
     for (int wave = 0; wave < 4; ++wave)
@@ -627,7 +652,13 @@ int pack_prologue_f16x3(msiren_ctx* h) {
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const int s2 = (msiren::EM_C3_KSTEPS / 2) * (wave >> 1) + ks, f = 32 * (wave & 1) + 16 * t + (lane & 15);
-                        const int k = (8 * (s2 >> 4) + j) * 64 + 4 * (s2 & 15) + (lane >> 4);
+                        int k;  // torch's flattened (channel, position) index of element (k-step s2, q = lane >> 4, j) of the conv kernel's images
+                        if (h->em_conv_mfma) {
+                            const int cw = s2 >> 4, cl = 4 * (s2 & 15) + (lane >> 4);  // the conv kernel's (wave, lane) that stored this piece
+                            k = (16 * (cw & 1) + 4 * (cl >> 4) + (j & 3)) * 64 + 16 * (2 * (cw >> 1) + (j >> 2)) + (cl & 15);
+                        } else {
+                            k = (8 * (s2 >> 4) + j) * 64 + 4 * (s2 & 15) + (lane >> 4);
+                        }
                         put(wave, ks, t, lane, j, std::ldexp((double)W3[(size_t)f * 2048 + k], a3));
                     }
     for (int f = 0; f < 64; ++f) bias[f] = B3[f];
@@ -1182,8 +1213,9 @@ int launch_prologue_f16x3_t(msiren_ctx* h, const float* tiles_dev, const float* 
         p.feat = (const msiren::em_u4*)c.feat.p;
         p.feat_inv = (const float*)((const char*)c.feat.p + (size_t)rows16 * 2048 * 4 + msiren::EM_MAX_DEPTH * 2048);
         h->enc.plan = h->plan;
-        hipLaunchKernelGGL(msiren::encoder_conv_f16x3_kernel<0>, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, (msiren::em_u4*)c.feat.p,
-                           (float*)((char*)c.feat.p + (size_t)rows16 * 2048 * 4 + msiren::EM_MAX_DEPTH * 2048));
+        float* const finv = (float*)((char*)c.feat.p + (size_t)rows16 * 2048 * 4 + msiren::EM_MAX_DEPTH * 2048);
+        if (h->em_conv_mfma) hipLaunchKernelGGL(msiren::encoder_conv_f16x3_kernel<1>, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, (msiren::em_u4*)c.feat.p, finv);
+        else hipLaunchKernelGGL(msiren::encoder_conv_f16x3_kernel<0>, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, (msiren::em_u4*)c.feat.p, finv);
         HIPCHK(hipGetLastError());
     }
     if (mods_dev) {
@@ -1613,6 +1645,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_TRACE_HOST")) h->trace_host = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_PROLOGUE_F16X3")) h->em_enabled = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_EM_DEPTH")) h->em_depth = std::atoi(e);
+    if (const char* e = std::getenv("MSIREN_CONV_MFMA")) h->em_conv_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_WS_TWO")) h->ws_two = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_HOST_SPLIT")) h->host_first_pct = std::max(5, std::min(95, std::atoi(e)));
     declare_expected(h);
@@ -1645,6 +1678,7 @@ int msiren_destroy(msiren_handle h) {
     if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
     if (h->d_wp16n) (void)hipFree(h->d_wp16n);
     if (h->d_emw) (void)hipFree(h->d_emw);
+    if (h->d_emc2) (void)hipFree(h->d_emc2);
     for (void* q : {h->d_woutx1, h->d_wpx1n, h->d_wpx1w, (void*)h->d_bias32x1})
         if (q) (void)hipFree(q);
     float* ptrs[] = {h->d_dump, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw, h->d_embias};
