@@ -105,8 +105,12 @@ __device__ __forceinline__ float em_absmax8(const em_f4 a, const em_f4 b) {
 // one CU streams 2.9 MB in 23 us from a warm L2 and in 30 us from the Infinity Cache once >= 8 k-steps per wave are in flight
 // (tools/l2_stream_probe.hip); the ring of 16 = 256 registers holds 1.5 us of stream, so that the fragments keep arriving
 // through a layer's epilogue -- row maxima, two barriers, the split -- during which no wave issues a load).
-template <int NPH, int NPZ, int DEPTH>
+// MODE: 1 = the encoder's tail only (features -> latent), 2 = the Modulator only (latent -> modulations), 3 = both, the latent
+// staying in the workgroup (compile-time: as a run-time choice the compiler hoisted the other branch's loads over the first stage
+// and spilled them).
+template <int NPH, int NPZ, int DEPTH, int MODE>
 __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void latent_mods_f16x3_kernel(EmTailParams p) {
+    constexpr bool ENC = (MODE & 1) != 0, MOD = (MODE & 2) != 0;
     constexpr int H = 128 * NPH, Z = 128 * NPZ;
     constexpr int KH = H / 32, KZ = Z / 32;           // k-steps of a hidden / latent image
     constexpr int ZIMG = 0, HIMG = Z * 4;             // em_u4 offsets: an image is K/32 k-steps x 128 em_u4
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
     // the stages whose count is a run-time value (L layers) must advance the position by a multiple of DEPTH per iteration
     static_assert((EM_C3_KSTEPS / 2) % DEPTH == 0 && (NPH * KZ) % DEPTH == 0 && (NPH * KH) % DEPTH == 0, "ring depth must divide every layer");
     constexpr int PHZ = (NPZ * EM_FC_KSTEPS) % DEPTH;  // ring phase at which the z stage (and every layer behind it) starts
+    constexpr bool EARLY = DEPTH > 2;  // fetch what an epilogue reads from global memory in front of its K loop (costs 8 registers)
     constexpr int BD = DEPTH < 8 ? DEPTH : 8;           // conv3's B images come from HBM / L2 as well: their own, shallower ring
     static_assert(H * 4 >= EM_FC_KSTEPS * 128 && Z * 4 >= 256, "the conv3 image and partial sums alias the H / Z images");
     extern __shared__ __attribute__((aligned(16))) em_u4 em_smem[];
@@ -135,9 +140,9 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
 
     // ---- the weight stream of this wave: ring[u] = fragments of k-step g + u, g = the k-step about to be consumed ----
     const em_u4* const wp = p.wstream + (size_t)wave * p.wave_stride + lane;
-    int g = p.feat ? 0 : p.zp_start;
+    int g = ENC ? 0 : p.zp_start;
     em_u4 ring[DEPTH][4];
-    if (p.feat) {
+    if constexpr (ENC) {
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u)
 #pragma unroll
@@ -171,17 +176,25 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
     auto pass_lds = [&](const em_u4* img, auto nk_c, auto ph0_c) {
         constexpr int NK = decltype(nk_c)::value, PH0 = decltype(ph0_c)::value;
         acc[0] = acc[1] = em_f4{0.f, 0.f, 0.f, 0.f};
-        em_u4 bh = img[0], bl = img[64];
+        if constexpr (DEPTH == 2) {  // (the instance that lives on 96 registers: no second B buffer)
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            em_u4 nh = bh, nl = bl;
-            if (k + 1 < NK) {
-                nh = img[(k + 1) * 128];
-                nl = img[(k + 1) * 128 + 64];
+            for (int k = 0; k < NK; ++k) {
+                const em_u4 bh = img[k * 128], bl = img[k * 128 + 64];
+                EM_KSTEP((PH0 + k) % DEPTH, bh, bl);
             }
-            EM_KSTEP((PH0 + k) % DEPTH, bh, bl);
-            bh = nh;
-            bl = nl;
+        } else {
+            em_u4 bh = img[0], bl = img[64];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                em_u4 nh = bh, nl = bl;
+                if (k + 1 < NK) {
+                    nh = img[(k + 1) * 128];
+                    nl = img[(k + 1) * 128 + 64];
+                }
+                EM_KSTEP((PH0 + k) % DEPTH, bh, bl);
+                bh = nh;
+                bl = nl;
+            }
         }
     };
     using em_zero = std::integral_constant<int, 0>;
@@ -200,11 +213,18 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
     float inv_z = 1.f;  // 2^-s of this lane's row in the Z image
     em_f4 held[NPH > NPZ ? NPH : NPZ][2];
 
-    if (p.feat) {
+    if constexpr (ENC) {
         // ---- conv3 == Linear(2048, 64): 4 tiles; wave = (tile pair w & 1, K half w >> 1); B = the conv kernel's images ----
         // (everything an epilogue reads from global memory is fetched BEFORE its K loop: behind it the load's whole latency would be exposed)
-        const float finv = p.feat_inv[row];
-        const em_f4 b3_0 = *reinterpret_cast<const em_f4*>(p.bias + 32 * (wave & 1) + 4 * q), b3_1 = *reinterpret_cast<const em_f4*>(p.bias + 32 * (wave & 1) + 16 + 4 * q);
+        // (the 96-register instance fetches them behind the loop: it runs beside a trunk, where latency is not what it is short of)
+        float finv;
+        em_f4 b3_0, b3_1;
+        auto fetch_c3 = [&]() {
+            finv = p.feat_inv[row];
+            b3_0 = *reinterpret_cast<const em_f4*>(p.bias + 32 * (wave & 1) + 4 * q);
+            b3_1 = *reinterpret_cast<const em_f4*>(p.bias + 32 * (wave & 1) + 16 + 4 * q);
+        };
+        if constexpr (EARLY) fetch_c3();
         {
             const em_u4* fb = p.feat + ((size_t)rb * EM_C3_KSTEPS + (size_t)(wave >> 1) * (EM_C3_KSTEPS / 2)) * 128 + lane;
             em_u4 bring[BD][2];
@@ -224,6 +244,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
                 }
             }
         }
+        if constexpr (!EARLY) fetch_c3();
         // zero k-steps 2, 3 of the conv3 image (the Linear's K = 64 is padded to the ring depth); partial sums of K half 1 -> LDS
         himg[2 * 128] = himg[2 * 128 + 64] = himg[3 * 128] = himg[3 * 128 + 64] = em_u4{0u, 0u, 0u, 0u};
         em_f4* const part = reinterpret_cast<em_f4*>(em_smem + ZIMG) + lane;  // [tile pair][tile][64 lanes]
@@ -261,10 +282,15 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
 #pragma unroll
         for (int pz = 0; pz < NPZ; ++pz) {
             static_assert(NPZ <= 2, "ring phases of the Linear's passes");
-            const em_f4 bf[2] = {*reinterpret_cast<const em_f4*>(p.bias + 64 + 128 * pz + 32 * wave + 4 * q),
-                                 *reinterpret_cast<const em_f4*>(p.bias + 64 + 128 * pz + 32 * wave + 16 + 4 * q)};
+            em_f4 bf[2];
+            auto fetch_fc = [&]() {
+                bf[0] = *reinterpret_cast<const em_f4*>(p.bias + 64 + 128 * pz + 32 * wave + 4 * q);
+                bf[1] = *reinterpret_cast<const em_f4*>(p.bias + 64 + 128 * pz + 32 * wave + 16 + 4 * q);
+            };
+            if constexpr (EARLY) fetch_fc();
             if (pz == 0) pass_lds(himg, std::integral_constant<int, EM_FC_KSTEPS>{}, em_zero{});
             else pass_lds(himg, std::integral_constant<int, EM_FC_KSTEPS>{}, std::integral_constant<int, EM_FC_KSTEPS % DEPTH>{});
+            if constexpr (!EARLY) fetch_fc();
             const float u = inv_a3 * p.winv_fc;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -290,7 +316,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
                 for (int t = 0; t < 2; ++t)
                     *reinterpret_cast<em_f4*>(p.z_out + (size_t)row * Z + 128 * pz + 32 * wave + 16 * t + 4 * q) = held[pz][t];
         }
-        if (!p.mods) return;  // encoder only (workgroup-uniform)
+        if constexpr (!MOD) return;  // encoder only
         float sc;
         row_scale(mine, 4, sc, inv_z);
 #pragma unroll
@@ -311,12 +337,17 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             static_assert(NPH == 2 || NPH == 4, "ring phases of a layer's passes");
-            const em_f4 bz[2] = {*reinterpret_cast<const em_f4*>(mbias + (size_t)l * H + 128 * ph + 32 * wave + 4 * q),
-                                 *reinterpret_cast<const em_f4*>(mbias + (size_t)l * H + 128 * ph + 32 * wave + 16 + 4 * q)};
+            em_f4 bz[2];
+            auto fetch_z = [&]() {
+                bz[0] = *reinterpret_cast<const em_f4*>(mbias + (size_t)l * H + 128 * ph + 32 * wave + 4 * q);
+                bz[1] = *reinterpret_cast<const em_f4*>(mbias + (size_t)l * H + 128 * ph + 32 * wave + 16 + 4 * q);
+            };
+            if constexpr (EARLY) fetch_z();
             if (ph == 0) pass_lds(zimg, std::integral_constant<int, KZ>{}, std::integral_constant<int, PHZ>{});
             else if (ph == 1) pass_lds(zimg, std::integral_constant<int, KZ>{}, std::integral_constant<int, (PHZ + KZ) % DEPTH>{});
             else if (ph == 2) pass_lds(zimg, std::integral_constant<int, KZ>{}, std::integral_constant<int, (PHZ + 2 * KZ) % DEPTH>{});
             else pass_lds(zimg, std::integral_constant<int, KZ>{}, std::integral_constant<int, (PHZ + 3 * KZ) % DEPTH>{});
+            if constexpr (!EARLY) fetch_z();
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 em_f4 v;
@@ -360,11 +391,17 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
         const float u = inv_h * p.winv_h[l];
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
-            const em_f4 c0 = cs[(size_t)((l - 1) * NPH + ph) * 512], c1 = cs[(size_t)((l - 1) * NPH + ph) * 512 + 64];
+            em_f4 c0, c1;
+            auto fetch_c = [&]() {
+                c0 = cs[(size_t)((l - 1) * NPH + ph) * 512];
+                c1 = cs[(size_t)((l - 1) * NPH + ph) * 512 + 64];
+            };
+            if constexpr (EARLY) fetch_c();
             if (ph == 0) pass_lds(himg, std::integral_constant<int, KH>{}, std::integral_constant<int, PHZ>{});
             else if (ph == 1) pass_lds(himg, std::integral_constant<int, KH>{}, std::integral_constant<int, (PHZ + KH) % DEPTH>{});
             else if (ph == 2) pass_lds(himg, std::integral_constant<int, KH>{}, std::integral_constant<int, (PHZ + 2 * KH) % DEPTH>{});
             else pass_lds(himg, std::integral_constant<int, KH>{}, std::integral_constant<int, (PHZ + 3 * KH) % DEPTH>{});
+            if constexpr (!EARLY) fetch_c();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v0 = __builtin_fmaf(acc[0][r], u, c0[r]), v1 = __builtin_fmaf(acc[1][r], u, c1[r]);

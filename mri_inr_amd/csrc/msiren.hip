@@ -1244,13 +1244,15 @@ int launch_prologue_f16x3_t(msiren_ctx* h, const float* tiles_dev, const float* 
     const bool alone = (h->nstreams == 1 || h->solo) && !h->overlap && h->trunk_force == 0 && !h->em_beside;
     int depth = alone ? (nblk <= (int64_t)h->num_cus ? 8 : 4) : 2;
     if (h->em_depth) depth = h->em_depth;
-    if constexpr (NPH > 2) {
-        hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 4>), dim3((unsigned)nblk), dim3(256), lds, c.s, p);
-    } else {
-        if (depth >= 8) hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 8>), dim3((unsigned)nblk), dim3(256), lds, c.s, p);
-        else if (depth >= 4) hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 4>), dim3((unsigned)nblk), dim3(256), lds, c.s, p);
-        else hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 2>), dim3((unsigned)nblk), dim3(256), lds, c.s, p);
-    }
+    // (the halves alone -- model.encoder(tiles), model.modulator(z) -- have the ring of 4 only)
+    const dim3 grid((unsigned)nblk), wg(256);
+    hipStream_t st = c.s;
+    if (tiles_dev && !mods_dev) hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 4, 1>), grid, wg, lds, st, p);
+    else if (!tiles_dev) hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 4, 2>), grid, wg, lds, st, p);
+    else if constexpr (NPH > 2) hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 4, 3>), grid, wg, lds, st, p);
+    else if (depth >= 8) hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 8, 3>), grid, wg, lds, st, p);
+    else if (depth >= 4) hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 4, 3>), grid, wg, lds, st, p);
+    else hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 2, 3>), grid, wg, lds, st, p);
     HIPCHK(hipGetLastError());
     return 0;
 }

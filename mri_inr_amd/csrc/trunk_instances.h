@@ -55,10 +55,14 @@ extern template __global__ void siren_trunk_x1w_kernel<1, 1, 0>(TrunkX1Params);
 extern template __global__ void siren_trunk_x1n_kernel<1, 1, 0, 3>(TrunkX1Params);
 extern template __global__ void siren_trunk_x1w_kernel<1, 1, 1>(TrunkX1Params);
 extern template __global__ void siren_trunk_x1n_kernel<1, 1, 1, 3>(TrunkX1Params);
-extern template __global__ void latent_mods_f16x3_kernel<2, 2, 2>(EmTailParams);
-extern template __global__ void latent_mods_f16x3_kernel<2, 2, 4>(EmTailParams);
-extern template __global__ void latent_mods_f16x3_kernel<2, 2, 8>(EmTailParams);
-extern template __global__ void latent_mods_f16x3_kernel<4, 1, 4>(EmTailParams);
+extern template __global__ void latent_mods_f16x3_kernel<2, 2, 2, 3>(EmTailParams);
+extern template __global__ void latent_mods_f16x3_kernel<2, 2, 4, 3>(EmTailParams);
+extern template __global__ void latent_mods_f16x3_kernel<2, 2, 8, 3>(EmTailParams);
+extern template __global__ void latent_mods_f16x3_kernel<2, 2, 4, 1>(EmTailParams);
+extern template __global__ void latent_mods_f16x3_kernel<2, 2, 4, 2>(EmTailParams);
+extern template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 3>(EmTailParams);
+extern template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 1>(EmTailParams);
+extern template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 2>(EmTailParams);
 extern template __global__ void encoder_conv_f16x3_kernel<0>(EncoderParams, const float*, em_u4*, float*);
 extern template __global__ void encoder_conv_f16x3_kernel<1>(EncoderParams, const float*, em_u4*, float*);
 }  // namespace msiren
