@@ -685,7 +685,7 @@ def scaling_selftest(args) -> int:
     return 0 if ok else 1
 
 
-def other_configs(launch_timeout=300.0):
+def other_configs(launch_timeout=90.0, wall_budget=240.0):
     """BASELINE.json configs 3, 4, 5 and the exact-fp32 trunk at N = 1, each measured by THIS script in a child process of its
     own behind the headline's timed region (device-resident tiles, random-init weights of the named architecture; the parent
     only waits): the numbers are those of the stand-alone commands, summarised.  (Measured in-process on further handles the
@@ -710,10 +710,17 @@ def other_configs(launch_timeout=300.0):
                                        "BASELINE configs[4]: deep residual 10x512, latent 128, bf16 MFMA (own semantics, parity unpinned)"),
     }
     out = {}
+    t_start = time.perf_counter()
     for name, (flags, what) in runs.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-extras"] + flags
+        # a side measurement must not delay the headline line without bound: a child gets at most `launch_timeout` seconds, all of them
+        # together `wall_budget` (each takes 10-20 s, mostly `import torch` on a fresh box); what does not fit is reported as skipped
+        left = wall_budget - (time.perf_counter() - t_start)
+        if left < 15.0:
+            out[name] = {"error": f"skipped: the side measurements' wall budget of {wall_budget:.0f} s is spent", "command": " ".join(cmd[1:])}
+            continue
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=launch_timeout)
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=min(launch_timeout, left))
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or len(lines) != 1:
                 out[name] = {"error": f"rc {r.returncode}: {r.stderr[-300:]}", "command": " ".join(cmd[1:])}

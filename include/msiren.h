@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define MSIREN_ABI_VERSION 1
+/* 2 (round 5): msiren_chain_* gone and msiren_profile_read_kernel / msiren_last_trunk_kernel / msiren_device_pci added in round 4 while the number
+ * stayed 1; sync no longer returns MSIREN_E_RANGE.  A library of another number refuses msiren_create. */
+#define MSIREN_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define MSIREN_API __attribute__((visibility("default")))

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSIREN_LIB") or os.path.join(_HERE, "libmsiren.so")  # MSIREN_LIB: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msiren.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ACT_SINE, ACT_MORLET = 0, 1
 PREC_F32, PREC_BF16, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
 E_INVALID, E_STATE, E_SHAPE, E_HIP, E_NOMEM, E_RANGE = -1, -2, -3, -4, -5, -6

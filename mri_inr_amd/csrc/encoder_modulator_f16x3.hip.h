@@ -436,6 +436,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
 
 template <int NPH, int NPZ>
 constexpr int em_tail_lds_bytes() { return (128 * NPZ * 4 + 128 * NPH * 4) * 16 + 256; }
+static_assert(em_tail_lds_bytes<2, 2>() <= 34 * 1024, "the H = Z = 256 instance runs beside the register-resident trunk: what its ring of 3 leaves free");
 
 // ---- conv1 + conv2 of the encoder, writing conv3's B images --------------------------------------------------------------
 // One workgroup per 32 x 32 tile.  The tile's 2048 conv2 features are scaled by the row's power of two, split, and stored as

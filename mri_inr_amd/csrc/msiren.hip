@@ -84,6 +84,9 @@ struct msiren_ctx {
     // which split-fp16 trunk a launch takes: 0 = launch_trunk_f16x3's own rule; 1 = register-resident with room beside it
     // (ring of 3); 2 = weight-stationary.  Set by forward_tiles_split around its two trunk launches.
     int trunk_force = 0;
+    hipEvent_t trunk_after = nullptr;  // the next trunk launch waits for this event first (a pipelined host call: the weight-stationary
+                                       // trunk of the last chunk behind the other stream's conditional launch, which cannot run beside it)
+    bool no_split = false;   // a host call that pipelines itself: its chunks are not cut again by forward_tiles_split
     bool em_beside = false;  // the prologue being launched runs beside a trunk of this call (forward_tiles_split): shallow weight ring
     int64_t split_min = 3200;  // MSIREN_SPLIT_MIN: *_dev forward calls of at least this many tiles are cut in two (0 = never)
     int split_pct = 12;        // MSIREN_SPLIT_PCT: share of the first part, percent
@@ -108,7 +111,7 @@ struct msiren_ctx {
     // f16x3 domain guard: a word in host memory the trunk kernels set when a scaled modulation does not fit fp16
     volatile int* status_host = nullptr;
     int* status_dev = nullptr;
-    int range_epoch = 0;           // number of the split-fp16 trunk launch in flight (what it writes to its stream's flag word)
+    unsigned range_epoch = 0;      // number of the split-fp16 trunk launch in flight (what it writes to its stream's flag word)
     int cond_rerun = 1;            // MSIREN_RANGE_RERUN=0 (A/B knob: what the conditional launch costs): f16x3 launches go unguarded
     int64_t range_events = 0;      // synchronisations that found the conditional exact-fp32 trunk had run, since create
     float* d_dump = nullptr;       // 256 floats: where lanes of the weight-stationary trunk that have nothing to store write
@@ -135,6 +138,8 @@ struct msiren_ctx {
     int cus_limit = 256;       // MSIREN_GRID: cap on the persistent grids
     int ring_force = 0;        // MSIREN_F16_RING: 3 / 4 forces the weight ring depth of the register-resident trunk
     int half_allowed = 1;      // MSIREN_F16_HALF=0: never use the half-unit instance
+    int host_pipe_min = 800;   // MSIREN_HOST_PIPE_MIN: tiles from which a host call pipelines itself (one slice: one chunk is as fast, profiles/r5)
+    int host_first = 112, host_piece = 400;  // MSIREN_HOST_FIRST / MSIREN_HOST_PIECE: tiles in the first / the further chunks of a pipelined host call
     int host_chunks = 0;       // MSIREN_HOST_CHUNKS: chunks a synchronous host call cuts itself into (0 = default)
     unsigned queue_start = 0;  // MSIREN_QUEUE_START: initial value of the never-reset pass counters
     // modulator: transposed weights so that consecutive threads read consecutive outputs
@@ -895,7 +900,7 @@ int launch_trunk_f16x3w(msiren_ctx* h, const float* mods_dev, int64_t B, float* 
     int rc = queue_for_launch(h, sch.npasses(), &p.pass_counter, &p.pass_base);
     if (rc) return rc;
     p.status = p.pass_counter + 16;  // the stream's flag word, behind the pass counter's line
-    p.status_val = h->range_epoch;
+    p.status_val = (int)h->range_epoch;
     const int lds = msiren::WsLds<4>::total(h->L);
     const bool mor = h->cfg.activation == MSIREN_ACT_MORLET;
     using Kern = void (*)(msiren::TrunkWsParams);
@@ -968,7 +973,7 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
         int rc = queue_for_launch(h, passes, &p.pass_counter, &p.pass_base);
         if (rc) return rc;
         p.status = p.pass_counter + 16;  // the stream's flag word, behind the pass counter's line
-        p.status_val = h->range_epoch;
+        p.status_val = (int)h->range_epoch;
         if (half) return queue_launched(h, r4 ? launch_trunk_f16x3h_r<4>(h, p, grid) : launch_trunk_f16x3h_r<3>(h, p, grid));
         return queue_launched(h, r4 ? launch_trunk_f16x3n_r<4>(h, p, grid) : launch_trunk_f16x3n_r<3>(h, p, grid));
     };
@@ -1123,7 +1128,7 @@ int launch_trunk_f32_cond(msiren_ctx* h, const float* mods_dev, int64_t B, float
     if (B * (int64_t)cpp > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     msiren::TrunkParams p = make_trunk_params(h, mods_dev, h->H, B, out_dev);  // (f16x3 needs H = 256 = HP: no padding of the rows)
     p.cond = (const int*)c.queue.p + 16;
-    p.cond_val = h->range_epoch;
+    p.cond_val = (int)h->range_epoch;
     p.items = (int)(B * cpp);
     p.host_flag = h->status_dev;
     const int grid = (int)std::min<int64_t>(p.items, (int64_t)h->num_cus);
@@ -1137,13 +1142,17 @@ int launch_trunk_f32_cond(msiren_ctx* h, const float* mods_dev, int64_t B, float
 
 int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     if (B == 0) return 0;
+    if (h->trunk_after) {
+        HIPCHK(hipStreamWaitEvent(h->sc[h->cur].s, h->trunk_after, 0));
+        h->trunk_after = nullptr;
+    }
     if (use_f16x3(h) || h->x1_ready) {
         hipEvent_t e1 = nullptr;
         {
             int rc = profile_begin(h, &e1);
             if (rc) return rc;
         }
-        if (!h->x1_ready && ++h->range_epoch <= 0) h->range_epoch = 1;  // this launch's number (never 0: the flag word's rest state)
+        if (!h->x1_ready && ++h->range_epoch == 0) h->range_epoch = 1;  // this launch's number (never 0: the flag word's rest state; unsigned: wraps)
         int rc = h->x1_ready ? launch_trunk_x1(h, mods_dev, B, out_dev) : launch_trunk_f16x3(h, mods_dev, B, out_dev);
         if (rc) return rc;
         if ((rc = profile_end(h, e1, B * h->P))) return rc;
@@ -1187,7 +1196,9 @@ int launch_linear(msiren_ctx* h, const msiren::ModulatorMfmaParams& mp) {
     // (default threshold: 1024 rows; a quarter of it for layers of >= 512 outputs -- at 400 rows the 16 x 16 kernel launches 800 workgroups
     //  per 512-wide layer and takes 10.8 us, the tiled one is 1.7 % of a config-5 step faster; 256-wide layers: 2.7 % slower.  Same bits.)
     const int tile_min = h->lin_tile_env || mp.H < 512 ? h->lin_tile_min : h->lin_tile_min / 4;
-    if (h->lin_tile_min > 0 && mp.B >= tile_min) {
+    // (the tiled kernel addresses rows with 32-bit element offsets: beyond 2^32 elements per operand the 16 x 16 kernel, same bits)
+    const bool fits32 = (uint64_t)mp.B * (uint64_t)std::max(std::max(mp.Z, mp.H), mp.Kh) < (1ULL << 32);
+    if (h->lin_tile_min > 0 && mp.B >= tile_min && fits32) {
         dim3 grid((unsigned)((mp.B + 31) / 32), (unsigned)((mp.H + 31) / 32));
         hipLaunchKernelGGL((msiren::linear_mfma_tile_kernel<2, 2>), grid, dim3(256), 0, s, mp);
     } else {
@@ -1241,7 +1252,7 @@ int launch_prologue_f16x3_t(msiren_ctx* h, const float* tiles_dev, const float* 
     const int lds = msiren::em_tail_lds_bytes<NPH, NPZ>();
     // ring depth 4 (more weight fragments in flight per wave) where the workgroups have their CUs to themselves; depth 2 (<= 96
     // registers, 33 KB of LDS) where they run beside the register-resident trunk of the other stream or many to a CU.  Same bits.
-    const bool alone = (h->nstreams == 1 || h->solo) && !h->overlap && h->trunk_force == 0 && !h->em_beside;
+    const bool alone = (h->nstreams == 1 || h->solo) && !h->overlap && !h->em_beside;
     int depth = alone ? (nblk <= (int64_t)h->num_cus ? 8 : 4) : 2;
     if (h->em_depth) depth = h->em_depth;
     // (the halves alone -- model.encoder(tiles), model.modulator(z) -- have the ring of 4 only)
@@ -1386,7 +1397,7 @@ int forward_latent_dev(msiren_ctx* h, const float* z_dev, int64_t B, float* out_
 // stay on the stream that produces and consumes them.  The call still "happens on its stream": inputs are read and
 // outputs written by work that the stream's tail depends on.
 bool use_split(msiren_ctx* h, int64_t B) {
-    return h->split_min > 0 && B >= h->split_min && (h->nstreams == 1 || h->solo) && !h->plan && !h->overlap && h->L == 5 && use_f16x3(h) &&
+    return h->split_min > 0 && B >= h->split_min && (h->nstreams == 1 || h->solo) && !h->plan && !h->overlap && !h->no_split && h->L == 5 && use_f16x3(h) &&
            !h->x1_ready && h->have_encoder && h->have_modulator && h->Z % 16 == 0 && ws_capable(h, B);
 }
 
@@ -1634,6 +1645,9 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_GRID")) h->cus_limit = std::max(1, std::min(h->num_cus, std::atoi(e)));
     if (const char* e = std::getenv("MSIREN_F16_RING")) h->ring_force = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_F16_HALF")) h->half_allowed = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_HOST_PIPE_MIN")) h->host_pipe_min = std::max(128, std::atoi(e));
+    if (const char* e = std::getenv("MSIREN_HOST_FIRST")) h->host_first = std::max(16, std::atoi(e));
+    if (const char* e = std::getenv("MSIREN_HOST_PIECE")) h->host_piece = std::max(64, std::atoi(e));
     if (const char* e = std::getenv("MSIREN_HOST_CHUNKS")) h->host_chunks = std::max(1, std::min(std::atoi(e), 16));
     if (const char* e = std::getenv("MSIREN_QUEUE_START")) h->queue_start = (unsigned)std::strtoul(e, nullptr, 0);
     if (const char* e = std::getenv("MSIREN_F16_WS")) h->f16_ws = std::atoi(e) != 0;
@@ -1880,57 +1894,93 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     if (B == 0) return 0;
     const size_t nt = (size_t)B * h->O * h->O * sizeof(float), no = (size_t)B * h->P * sizeof(float);
     if ((rc = ensure(h, h->ws_tiles, nt)) || (rc = ensure(h, h->ws_out, no))) return rc;
-    // One chunk on one stream (the weight-stationary trunk, alone on the chip) is the default.  MSIREN_HOST_CHUNKS=2 cuts the
-    // batch in two over the two streams -- the second part's upload runs beside the first part's kernels, the first part's
-    // download beside the second part's trunk -- which was the default while the register-resident trunk was the only one
-    // (round 2: 460 us per 400 tiles against 490 on one stream); with the weight-stationary trunk one chunk is as fast or
-    // faster (461-469 us against 469-481, same box, three handles each) and does not depend on where the two streams land
-    // (one handle in six ran the two-chunk form at 573 us).  (More than two chunks do not help: a pageable copy waits for
-    // its stream to drain.)  Patches are independent: the cut does not change results.
-    int nchunks = 1;
-    if (h->host_chunks) nchunks = h->host_chunks;
-    nchunks = (int)std::min<int64_t>(nchunks, B);
+    // The call pipelines itself (round 5).  The device side of a slice is ~325 us; uploading its 1.6 MB first and downloading
+    // its 0.9 MB afterwards added ~90 us in front and behind.  Patches are independent (modulated_siren.py:435-457), so the
+    // batch is cut into chunks that alternate between the handle's two streams:
+    //     H2D_0 | launch_0 | H2D_1 | launch_1 | D2H_0 | H2D_2 | launch_2 | D2H_1 | ... | D2H_last
+    // (a pageable copy blocks the host until it is done -- so each is issued where the device has other work queued).
+    // Chunk 0 is SMALL (112 tiles = two rounds of the register-resident trunk): its upload is short, so the device starts early,
+    // and its trunk runs while the next chunk's tiles arrive and its encoder / Modulator run beside it.  From 800 tiles (two slices)
+    // up: 8 slices per call 2.57 -> 2.27 ms (318 -> 361 Mpixel/s); a single slice is as fast in one chunk (428 us either way: the
+    // second chunk's encoder + Modulator, 73 us beside the first chunk's trunk, end up on the critical path) --
+    // profiles/r5/04_host_call_pipelining.txt.  Every chunk but the
+    // last takes the register-resident trunk (room beside it for the next chunk's prologue), the last one the weight-stationary
+    // trunk (the faster kernel; nothing is left to run beside it but the previous chunk's download).  All trunk and prologue
+    // instances give the same bits, so the cut does not change results (tests/test_gpu_split.py).
+    // MSIREN_HOST_CHUNKS=1: one chunk on one stream (rounds 3-4); =2 with MSIREN_HOST_SPLIT: the even two-chunk cut of round 2.
+    struct Chunk { int64_t lo, n; int stream, trunk; bool beside; };
+    std::vector<Chunk> plan;
     const int cur0 = h->cur;
+    const bool pipelined = h->host_chunks == 0 && B >= h->host_pipe_min && use_f16x3(h) && !h->x1_ready && h->L == 5 && h->em_enc && h->em_mod && ws_capable(h, B);
+    if (pipelined) {
+        const int64_t first = std::min<int64_t>(h->host_first, B - 64), piece = h->host_piece;
+        plan.push_back({0, first, cur0, 1, false});
+        for (int64_t lo = first; lo < B;) {
+            int64_t n = std::min<int64_t>(piece, B - lo);
+            if (B - lo - n < 128) n = B - lo;  // (no tiny last chunk)
+            const bool last = lo + n == B;
+            plan.push_back({lo, n, (int)(plan.size() & 1) ^ cur0, last ? 2 : 1, true});
+            lo += n;
+        }
+    } else {
+        int nchunks = std::max(1, h->host_chunks);
+        nchunks = (int)std::min<int64_t>(nchunks, B);
+        auto bound = [&](int k) -> int64_t {  // equal parts, except that two chunks may be cut unevenly (host_first_pct)
+            if (nchunks == 2 && k == 1) return std::max<int64_t>(1, std::min<int64_t>(B - 1, B * h->host_first_pct / 100));
+            return B * k / nchunks;
+        };
+        for (int k = 0; k < nchunks; ++k) plan.push_back({bound(k), bound(k + 1) - bound(k), nchunks > 1 ? (k & 1) : cur0, 0, false});
+    }
+    const int nchunks = (int)plan.size();
     const size_t tile_elems = (size_t)h->O * h->O;
-    // chunk boundaries: equal parts, except that two chunks may be cut unevenly (host_first_pct)
-    auto bound = [&](int k) -> int64_t {
-        if (nchunks == 2 && k == 1) return std::max<int64_t>(1, std::min<int64_t>(B - 1, B * h->host_first_pct / 100));
-        return B * k / nchunks;
-    };
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     auto us = [&]() { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
-    double tr[40];
-    int ntr = 0;
-    h->overlap = nchunks > 1;
-    SoloCall solo(h, nchunks == 1);
+    std::vector<double> tr_h2d(nchunks, 0.0), tr_launch(nchunks, 0.0), tr_d2h(nchunks, 0.0);
+    h->overlap = !pipelined && nchunks > 1;
+    SoloCall solo(h, nchunks == 1 || pipelined);
+    struct Restore {  // the launchers address the stream through h->cur, the trunk through h->trunk_force, the prologue's ring through h->em_beside
+        msiren_ctx* h;
+        int cur;
+        ~Restore() { h->cur = cur; h->trunk_force = 0; h->em_beside = false; h->overlap = false; h->no_split = false; h->trunk_after = nullptr; }
+    } restore{h, cur0};
+    h->no_split = pipelined;
+    auto download = [&](int k) {
+        const Chunk& c = plan[k];
+        hipError_t e = hipMemcpyAsync(out_host + (size_t)c.lo * h->P, (float*)h->ws_out.p + (size_t)c.lo * h->P, (size_t)c.n * h->P * sizeof(float),
+                                      hipMemcpyDeviceToHost, h->sc[c.stream].s);
+        if (e != hipSuccess && !rc) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(D2H): %s", hipGetErrorString(e));
+        tr_d2h[k] = us();
+    };
     for (int k = 0; k < nchunks && !rc; ++k) {
-        const int64_t lo = bound(k), n = bound(k + 1) - lo;
-        h->cur = nchunks > 1 ? (k & 1) : cur0;
-        float* d_t = (float*)h->ws_tiles.p + (size_t)lo * tile_elems;
-        hipError_t e = hipMemcpyAsync(d_t, tiles_host + (size_t)lo * tile_elems, (size_t)n * tile_elems * sizeof(float),
-                                      hipMemcpyHostToDevice, h->sc[h->cur].s);
+        const Chunk& c = plan[k];
+        h->cur = c.stream;
+        h->trunk_force = c.trunk;
+        h->em_beside = c.beside;
+        float* d_t = (float*)h->ws_tiles.p + (size_t)c.lo * tile_elems;
+        hipError_t e = hipMemcpyAsync(d_t, tiles_host + (size_t)c.lo * tile_elems, (size_t)c.n * tile_elems * sizeof(float), hipMemcpyHostToDevice, h->sc[c.stream].s);
         if (e != hipSuccess) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(H2D): %s", hipGetErrorString(e));
-        if (ntr < 38) tr[ntr++] = us();
-        if (!rc) rc = forward_tiles_dev(h, d_t, n, (float*)h->ws_out.p + (size_t)lo * h->P);
-        if (ntr < 38) tr[ntr++] = us();
+        tr_h2d[k] = us();
+        // (the weight-stationary trunk owns its CUs: queued beside the previous chunk's conditional exact-fp32 launch it would start first,
+        //  and that launch -- and the download behind it -- would wait for it to end)
+        if (pipelined && c.trunk == 2 && k >= 1 && !rc) h->trunk_after = h->sc[plan[k - 1].stream].ev_join;
+        if (!rc) rc = forward_tiles_dev(h, d_t, c.n, (float*)h->ws_out.p + (size_t)c.lo * h->P);
+        if (pipelined && !rc) {
+            auto& sc = h->sc[c.stream];
+            if (!sc.ev_join) { hipError_t e2 = hipEventCreateWithFlags(&sc.ev_join, hipEventDisableTiming); if (e2 != hipSuccess) rc = fail(MSIREN_E_HIP, "hipEventCreate: %s", hipGetErrorString(e2)); }
+            if (!rc) { hipError_t e2 = hipEventRecord(sc.ev_join, sc.s); if (e2 != hipSuccess) rc = fail(MSIREN_E_HIP, "hipEventRecord: %s", hipGetErrorString(e2)); }
+        }
+        tr_launch[k] = us();
+        // (pipelined: the previous chunk's download is issued once this chunk's work is queued behind it on the other stream;
+        //  otherwise all downloads follow all launches, as a pageable D2H blocks the host until its chunk is done)
+        if (pipelined && k >= 1 && !rc) download(k - 1);
     }
-    // downloads are enqueued after ALL launches: a pageable D2H blocks the host until its chunk is done
-    for (int k = 0; k < nchunks && !rc; ++k) {
-        const int64_t lo = bound(k), n = bound(k + 1) - lo;
-        h->cur = nchunks > 1 ? (k & 1) : cur0;
-        hipError_t e = hipMemcpyAsync(out_host + (size_t)lo * h->P, (float*)h->ws_out.p + (size_t)lo * h->P,
-                                      (size_t)n * h->P * sizeof(float), hipMemcpyDeviceToHost, h->sc[h->cur].s);
-        if (e != hipSuccess) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(D2H): %s", hipGetErrorString(e));
-        if (ntr < 38) tr[ntr++] = us();
-    }
-    h->overlap = false;
+    for (int k = pipelined ? nchunks - 1 : 0; k < nchunks && !rc; ++k) download(k);
     h->cur = cur0;
     const int rs = sync_all(h);
     if (h->trace_host) {
-        std::fprintf(stderr, "msiren_forward_tiles B=%lld chunks=%d (us since entry): ", (long long)B, nchunks);
-        for (int k = 0; k < nchunks; ++k) std::fprintf(stderr, "h2d%d %.0f launched%d %.0f  ", k, tr[2 * k], k, tr[2 * k + 1]);
-        for (int k = 0; k < nchunks; ++k) std::fprintf(stderr, "d2h%d %.0f  ", k, tr[2 * nchunks + k]);
+        std::fprintf(stderr, "msiren_forward_tiles B=%lld chunks=%d%s (us since entry): ", (long long)B, nchunks, pipelined ? " pipelined" : "");
+        for (int k = 0; k < nchunks; ++k) std::fprintf(stderr, "[%lld tiles: h2d %.0f launched %.0f d2h %.0f] ", (long long)plan[k].n, tr_h2d[k], tr_launch[k], tr_d2h[k]);
         std::fprintf(stderr, "synced %.0f\n", us());
     }
     return rc ? rc : rs;

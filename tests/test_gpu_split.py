@@ -170,3 +170,61 @@ def test_tiled_linear_layers_same_bits_as_the_16x16_kernel(H, Z, L, B):
     if H == 256:
         imgs = np.stack([syn.make_slice(k, brain_mask=True) for k in range(5)])
         assert np.array_equal(small.reconstruct(imgs), tiled.reconstruct(imgs))
+
+
+def test_host_call_of_several_slices_pipelines_itself_same_bits():
+    """A numpy -> numpy call of >= 800 tiles cuts itself into chunks over the handle's two streams (uploads and downloads beside the
+    other chunk's kernels; msiren_forward_tiles_impl).  Patches are independent and every trunk / prologue instance gives the same
+    bits, so nothing may change -- also with asynchronous *_dev work still pending on the helper stream of a two-stream handle."""
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    B = 1339
+    tiles = np.random.default_rng(17).random((B, 32, 32), dtype=np.float32)
+    one = make_with_env(sd, {"MSIREN_HOST_CHUNKS": 1, "MSIREN_SPLIT_MIN": 0}, precision="f16x3")
+    ref = one(tiles)
+    check(ref[:24], orc.modulated_siren_forward(sd, tiles[:24], num_layers=5, dtype=np.float64))
+    for env in ({}, {"MSIREN_HOST_FIRST": 56, "MSIREN_HOST_PIECE": 200}, {"MSIREN_HOST_PIPE_MIN": 128, "MSIREN_HOST_FIRST": 40}):
+        m = make_with_env(sd, env, precision="f16x3")
+        _lib.check(m._lib.msiren_profile_enable(m._h, 1))
+        assert np.array_equal(m(tiles), ref), env
+        ks = {k["kernel"]: k for k in m.profile_kernels()}
+        assert set(ks) == {"siren_trunk_f16x3n_kernel<0,3,5>", "siren_trunk_f16x3w_kernel<0,4>"} and sum(k["coords"] for k in ks.values()) == B * 576, ks
+        assert ks["siren_trunk_f16x3w_kernel<0,4>"]["launches"] == 1      # the last chunk
+        assert np.array_equal(m(tiles[:500]), ref[:500])                    # (below the threshold with the default knobs: one chunk)
+        # two-stream handle, un-synced device calls on both streams, then the host call
+        _lib.check(m._lib.msiren_set_streams(m._h, 2))
+        d_in = m.device_array((400, 32, 32)).copy_from(tiles[:400])
+        d_out = [m.device_array((400, 24, 24)) for _ in range(3)]
+        for k in range(3):
+            run_dev(m, d_in, 400, d_out[k])
+        assert np.array_equal(m(tiles), ref), env
+        m.sync()
+        for o in d_out:
+            assert np.array_equal(o.numpy(), ref[:400])
+        _lib.check(m._lib.msiren_set_streams(m._h, 1))
+
+
+def test_out_of_domain_modulation_in_the_second_part_of_a_cut_call():
+    """A >= 3200-tile call on a one-stream handle is cut in two (forward_tiles_split); a tile whose modulations leave the fp16
+    domain lies in the SECOND part: that part's launch is repaired by the conditional exact-fp32 trunk (which reads mods2 with
+    p.B = B1), the first part keeps its split-fp16 bits."""
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    B = 3300
+    tiles = np.random.default_rng(23).random((B, 32, 32), dtype=np.float32)
+    m = make_model(sd, precision="f16x3")
+    clean = m(tiles)
+    bad = tiles.copy()
+    bad[3000] *= 3e7          # latent ~1e7 -> modulations far beyond 65504
+    z = m.encoder(bad)
+    mods = np.stack(m.modulator(z), 0)
+    assert np.abs(mods[:, 3000]).max() > 1e5 and np.isfinite(mods).all()
+    B0 = (B * 12 // 100 + 15) // 16 * 16                      # forward_tiles_split's first part (MSIREN_SPLIT_PCT = 12)
+    d_in, d_out = m.device_array(bad.shape).copy_from(bad), m.device_array((B, 24, 24))
+    _lib.check(m._lib.msiren_profile_enable(m._h, 1))
+    run_dev(m, d_in, B, d_out)
+    m.sync()
+    assert len(m.profile_kernels()) == 2                       # the call was cut
+    got = d_out.numpy()
+    exact = make_model(sd, precision="fp32")
+    assert np.array_equal(got[:B0], clean[:B0])                                  # first part: untouched
+    assert np.array_equal(got[B0:], exact.forward_mods(mods[:, B0:]))            # second part: the exact-fp32 trunk's bits
+    assert np.isfinite(got).all()
