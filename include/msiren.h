@@ -66,7 +66,11 @@ enum {
                              outside what fp16 operands can carry is followed, on the same stream, by the
                              exact-fp32 trunk over the same batch (a conditional launch: "Domain guard"
                              below) -- the output is the reference's fp32 result either way. */
-    MSIREN_PREC_F16 = 3   /* as BF16 with fp16 operands (11-bit significand)                        */
+    MSIREN_PREC_F16 = 3   /* as BF16 with fp16 operands (11-bit significand).  fp16 ends at 65 504 where the
+                             reference's fp32 does not: a launch that stores a non-finite output (an overflow
+                             to inf is NaN one sine later) is followed, on the same stream, by the exact-fp32
+                             trunk over the same batch as a conditional launch -- outside the fp16 domain the
+                             output is the fp32 trunk's, bit for bit (round 5)                          */
 };
 
 /*

@@ -1025,6 +1025,8 @@ int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_
     const int64_t npasses = ws ? (int64_t)sch.n4 + sch.n2 : (units + 3) / 4;
     int rc = queue_for_launch(h, npasses, &p.pass_counter, &p.pass_base);
     if (rc) return rc;
+    p.status = p.pass_counter + 16;  // the stream's flag word, behind the pass counter's line (fp16 operands: the domain guard)
+    p.status_val = (int)h->range_epoch;
     return queue_launched(h, launch_trunk_x1_kernel(h, p, grid));
 }
 
@@ -1152,11 +1154,26 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
             int rc = profile_begin(h, &e1);
             if (rc) return rc;
         }
-        if (!h->x1_ready && ++h->range_epoch == 0) h->range_epoch = 1;  // this launch's number (never 0: the flag word's rest state; unsigned: wraps)
+        const bool x1_f16 = h->x1_ready && h->cfg.precision == MSIREN_PREC_F16;  // (bf16 has fp32's exponent range: nothing to guard)
+        if ((!h->x1_ready || x1_f16) && ++h->range_epoch == 0) h->range_epoch = 1;  // this launch's number (never 0: the flag word's rest state; unsigned: wraps)
         int rc = h->x1_ready ? launch_trunk_x1(h, mods_dev, B, out_dev) : launch_trunk_f16x3(h, mods_dev, B, out_dev);
         if (rc) return rc;
         if ((rc = profile_end(h, e1, B * h->P))) return rc;
-        return (h->x1_ready || !h->cond_rerun) ? 0 : launch_trunk_f32_cond(h, mods_dev, B, out_dev);
+        if (!h->cond_rerun) return 0;
+        if (x1_f16) {  // H = 512: the 64-coordinate exact-fp32 trunk as the conditional launch (its workgroups read the flag word and leave)
+            const int chunks = (h->P + 63) / 64;
+            if (B * (int64_t)chunks > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
+            msiren::TrunkParams p = make_trunk_params(h, mods_dev, h->H, B, out_dev);
+            p.cond = (const int*)h->sc[h->cur].queue.p + 16;
+            p.cond_val = (int)h->range_epoch;
+            p.host_flag = h->status_dev;
+            char keep[sizeof h->last_trunk];
+            std::memcpy(keep, h->last_trunk, sizeof keep);  // (the profile names the 16-bit trunk, not its stand-in)
+            rc = launch_trunk_hp<512>(h, p, (int)(B * chunks));
+            std::memcpy(h->last_trunk, keep, sizeof keep);
+            return rc;
+        }
+        return h->x1_ready ? 0 : launch_trunk_f32_cond(h, mods_dev, B, out_dev);
     }
     const int chunks = (h->P + 63) / 64;
     if (B * (int64_t)chunks > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);

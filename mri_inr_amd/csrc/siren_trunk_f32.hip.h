@@ -347,6 +347,11 @@ __device__ __forceinline__ void siren_trunk_f32_item(const TrunkParams& p, const
 
 template <int HP, int ACT, int RES, int DBG = 0>
 __global__ __launch_bounds__(256, (HP <= 256 ? 2 : 1)) void siren_trunk_f32_kernel(TrunkParams p) {
+    // (as a conditional launch behind a single-product fp16 trunk, H = 512: leave unless that launch wrote its number to *cond)
+    if (p.cond) {
+        if (__builtin_amdgcn_readfirstlane(*p.cond) != p.cond_val) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && p.host_flag) *p.host_flag = 1;
+    }
     siren_trunk_f32_item<HP, ACT, RES, DBG>(p, (int)blockIdx.x);
 }
 

@@ -35,6 +35,11 @@ struct TrunkX1Params {
     const int* plan;          // optional (compact_flags_kernel): the unit count is plan[1] (<= total_units)
     int* pass_counter;        // work queue (never reset: the host passes the value it holds at launch)
     unsigned pass_base;
+    // fp16 operands only (BF = 0): a launch that stores a non-finite output writes its own number to *status -- an activation,
+    // a modulation or a residual sum beyond fp16's 65 504 became inf, and inf is NaN one sine later, where the reference's fp32
+    // stays finite; the conditional exact-fp32 launch behind it (siren_trunk_f32_kernel with p.cond) then redoes the batch
+    int* status;
+    int status_val;
 };
 
 constexpr int X1_CHUNK_BYTES = 32768;

@@ -431,7 +431,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1n_kernel(TrunkX1Params p
             const float sv = q == 0 ? s0v : s1v;
             const int pc = q == 0 ? pc0 : pc1;
             const bool pv = q == 0 ? pv0 : pv1;
-            if (q < 2 && pv) p.out[(size_t)b * p.P + pc] = sin_rev(sv + p.bout);
+            const float o_ = sin_rev(sv + p.bout);
+            if (q < 2 && pv) {
+                p.out[(size_t)b * p.P + pc] = o_;
+                if constexpr (!BF) {
+                    if (!(__builtin_fabsf(o_) <= 2.f) && p.status) *p.status = p.status_val;  // NaN: the fp16 domain was left (or the input was NaN)
+                }
+            }
         }
         cur_pass = __builtin_amdgcn_readfirstlane(qslot[(pass + 1) & 1]);
     }

@@ -566,7 +566,13 @@ __global__ __launch_bounds__(256, 1) void siren_trunk_x1w_kernel(TrunkX1Params p
             if (u == 1) { pu = patch[1]; cu = c0[1]; lv = live[1]; }
             if (u == 2) { pu = patch[2]; cu = c0[2]; lv = live[2]; }
             if (u == 3) { pu = patch[3]; cu = c0[3]; lv = live[3]; }
-            if (lv && cu + c < P) p.out[(size_t)pu * P + cu + c] = sin_rev(s + p.bout);
+            const float o_ = sin_rev(s + p.bout);
+            if (lv && cu + c < P) {
+                p.out[(size_t)pu * P + cu + c] = o_;
+                if constexpr (!BF) {
+                    if (!(__builtin_fabsf(o_) <= 2.f) && p.status) *p.status = p.status_val;  // NaN: the fp16 domain was left (or the input was NaN)
+                }
+            }
         }
         cur_pass = __builtin_amdgcn_readfirstlane(qslot[pass & 1]);
     }

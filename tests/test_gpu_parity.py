@@ -439,6 +439,48 @@ def test_config5_16bit_trunk_vs_own_oracle(prec, res, act, tol):
     assert nerr(m32.forward_mods(mods).reshape(B, -1), ref) < 1e-4
 
 
+@pytest.mark.parametrize("res,L,mod", [(True, 10, 3e5), (True, 10, 1.0), (False, 4, 1e6), (True, 2, 2e5)])
+def test_f16_single_product_domain_identical_to_fp32_outside_it(res, L, mod):
+    """MSIREN_PREC_F16 (H = 512, fp16 operands, one product): activations, modulations and residual sums are rounded to fp16, and
+    beyond 65 504 that is inf -- NaN one sine later -- where the reference's fp32 arithmetic stays finite.  A launch that stores a
+    non-finite output raises its stream's flag, and the exact-fp32 trunk, enqueued behind it as a conditional launch, redoes
+    the batch: outside the domain the buffer holds the exact-fp32 trunk's bits, inside it the fp16 kernel's own (both the
+    weight-stationary kernel and, at num_layers = 2, the register-resident one), on the synchronous and the asynchronous API."""
+    H, Z, B = 512, 128, 11
+    sd = syn.make_state_dict(seed=27, dim_hidden=H, num_layers=L, latent_dim=Z, with_encoder=False)
+    sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
+    kw = dict(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=1.0, w0_initial=30.0, use_bias=True, dropout=0.1,
+              modulate=True, encoder_type="custom", encoder_path=None, outer_patch_size=32, inner_patch_size=16, siren_patch_size=24,
+              device="cuda", activation="sine", residual=res)
+    m, f = ModulatedSiren(**kw, precision="f16"), ModulatedSiren(**kw)
+    for mm in (m, f):
+        mm.load_state_dict(sd, strict=False)
+        mm.to("cuda")
+    small = syn.make_mods(8, L, B, H, lo=0.1, hi=0.6)
+    mods = (small * np.float32(mod)).astype(np.float32)
+    want = f.forward_mods(mods)
+    assert np.isfinite(want).all()
+    got = m.forward_mods(mods)
+    inside = m.forward_mods(small)
+    ref_small = orc.siren_forward(sd, small, num_layers=L, residual=res, dtype=np.float64)
+    assert np.isfinite(inside).all() and nerr(inside.reshape(B, -1), ref_small) <= 8e-3
+    if mod > 100:
+        assert np.array_equal(got, want)          # repaired: bit for bit the exact-fp32 trunk
+    else:
+        assert np.array_equal(got, inside)        # inside the domain nothing is redone
+        assert not np.array_equal(got, want)
+    # asynchronous entry point, flagged and clean launches interleaved on both streams
+    _lib_ = __import__("mri_inr_amd")._lib
+    _lib_.check(m._lib.msiren_set_streams(m._h, 2))
+    d_big, d_small = m.device_array(mods.shape).copy_from(mods), m.device_array(small.shape).copy_from(small)
+    outs = [m.device_array((B, 24, 24)) for _ in range(6)]
+    for k in range(6):
+        _lib_.check(m._lib.msiren_forward_mods_dev(m._h, (d_big if k % 2 == 0 else d_small).ptr, B, outs[k].ptr))
+    m.sync()
+    for k in range(6):
+        assert np.array_equal(outs[k].numpy(), got if k % 2 == 0 else inside), k
+
+
 @pytest.mark.parametrize("L,B", [(2, 5), (3, 5), (11, 3)])
 def test_16bit_trunk_depth_range_vs_own_oracle(L, B):
     """The single-product trunk at its depth limits: num_layers = 2 runs the register-resident kernel (the weight-stationary

@@ -69,18 +69,24 @@ def test_rank_dying_inside_the_broadcast_takes_the_job_down_within_30_s(tmp_path
     also when a survivor does not react to SIGTERM (blocked in native code with the signal ignored -> SIGKILL after 10 s)."""
     p = tmp_path / "bcast.py"
     p.write_text(textwrap.dedent("""
-        import ctypes, os, signal, sys
+        import ctypes, os, signal, sys, time
         sys.path.insert(0, %r)
         from mri_inr_amd.launch import exchange_from_rank0
         r = int(os.environ["RANK"])
         exchange_from_rank0(b"id" if r == 0 else None, timeout=60)      # the bootstrap succeeds on every rank
-        print("rank", r, "enters the broadcast", file=sys.stderr, flush=True)
-        if r == 2:
-            os.kill(os.getpid(), signal.SIGKILL)                        # dies inside the collective
         if r == 1:
             signal.signal(signal.SIGTERM, signal.SIG_IGN)               # a survivor that cannot be asked nicely
+        print("rank", r, "enters the broadcast", file=sys.stderr, flush=True)
+        open(os.path.join(%r, "in.%%d" %% r), "w").close()
+        if r == 2:
+            # dies inside the collective -- once the other two are in it as well (on a busy box the launcher, rightly, takes the
+            # job down the moment this rank is gone: a rank that has not printed yet would never be seen entering)
+            t0 = time.monotonic()
+            while not all(os.path.exists(os.path.join(%r, "in.%%d" %% k)) for k in (0, 1)) and time.monotonic() - t0 < 60:
+                time.sleep(0.01)
+            os.kill(os.getpid(), signal.SIGKILL)
         ctypes.CDLL(None).sleep(600)                                    # blocked in native code, like ncclBroadcast
-    """) % ROOT)
+    """) % (ROOT, str(tmp_path), str(tmp_path)))
     err = io.StringIO()
     t0 = time.monotonic()
     rc, _ = launch.spawn_ranks([sys.executable, str(p)], 3, timeout=300, stdout=io.StringIO(), stderr=err)
