@@ -180,14 +180,16 @@ def _scan_loads_in_flight(body, agprs=False):
         if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
             out = []
             continue
-        touched = set(r for o in ops for r in _regs(o, agprs=agprs))
+        is_vm_load = op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load")) and "_lds_" not in op
+        # (the destination of a LATER load may overlap an earlier one's: loads return in order, the later data lands last)
+        touched = set(r for o in (ops[1:] if is_vm_load else ops) for r in _regs(o, agprs=agprs))
         for rec in out:
             hit = touched & rec[2]
             if hit:
                 bad.append(f"v{sorted(hit)[0]} touched by `{raw.strip()}` (line {i + 1}) while `{rec[1].strip()}` (line {rec[0] + 1}) may be in flight")
                 rec[2] -= hit
-        if op.startswith(("global_", "buffer_", "flat_")):
-            returns = (op.startswith(("global_load", "buffer_load", "flat_load")) and "_lds_" not in op) or \
+        if op.startswith(("global_", "buffer_", "flat_", "scratch_")):   # (spill code counts on vmcnt like any other vector-memory operation)
+            returns = is_vm_load or \
                       (op.startswith("global_atomic") and "sc0" in raw)   # (global_load_lds_*: the VGPR operand is the address)
             dst = set(_regs(ops[0], agprs=agprs)) if (returns and ops and ops[0].startswith(("v", "a") if agprs else "v")) else set()
             seen += bool(dst)
@@ -248,6 +250,19 @@ def _scan_valu_sgpr_to_vmem(body, need=5):
                     seen += 1
                     if r in wrote and state - wrote[r] - 1 < need:
                         bad.append(f"`{line}` (line {i + 1}) reads s{r} {state - wrote[r] - 1} wait states after a VALU wrote it")
+        # round 5: the two other consumers of a VALU-written SGPR that need software wait states on gfx9 -- the lane select of
+        # v_readlane_b32 / v_writelane_b32 (4) and VCC as read by v_div_fmas (4).  (An asm statement that takes a freshly
+        # v_readfirstlane'd value as its lane select, or follows a compiler-issued VOP3 compare with v_div_fmas, gets no padding.)
+        if op in ("v_readlane_b32", "v_writelane_b32") and len(ops) >= 3:
+            for r in _sregs(ops[2]):
+                if r in wrote and state - wrote[r] - 1 < 4:
+                    bad.append(f"`{line}` (line {i + 1}) takes its lane from s{r} {state - wrote[r] - 1} wait states after a VALU wrote it")
+        if op.startswith("v_div_fmas"):
+            for r in (106, 107):
+                if r in wrote and state - wrote[r] - 1 < 4:
+                    bad.append(f"`{line}` (line {i + 1}) reads vcc {state - wrote[r] - 1} wait states after a VALU wrote it")
+        if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+            pass
         elif op.startswith("v_") and ops:
             for o in ops[:2] if op.startswith(("v_add_co", "v_sub_co", "v_subrev_co", "v_addc", "v_subb", "v_div_scale", "v_mad_u64", "v_mad_i64")) else ops[:1]:
                 for r in _sregs(o):
@@ -257,6 +272,62 @@ def _scan_valu_sgpr_to_vmem(body, need=5):
                 wrote.pop(r, None)   # (an SALU result is interlocked)
         state += 1
     return bad, seen
+
+
+def _scan_lds_reads_in_flight(body):
+    """The LDS side of _scan_loads_in_flight (round 5): a ds_read's destination may be read or overwritten only behind an
+    s_waitcnt lgkmcnt that covers it.  The counter is shared by LDS operations (in order among themselves) and scalar loads
+    (out of order): with a scalar load outstanding only lgkmcnt(0) proves anything -- which is what the compiler emits, for the
+    operations it KNOWS about; an LDS read or scalar load inside an asm statement is invisible to it, and a counted wait it
+    computed without them can be satisfied early.  Program order, every kernel of the built library.
+    Returns (violations, LDS reads seen)."""
+    out, bad, seen = [], [], 0   # outstanding lgkm operations, oldest first: [line, text, destination VGPRs, is_smem]
+    for i, raw in enumerate(body.splitlines()):
+        line = raw.split("//")[0].split(";")[0].strip()
+        if not line or line.endswith(":") or line.startswith("."):
+            continue
+        parts = line.split(None, 1)
+        op = parts[0]
+        ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        ops = [o.split()[0] if o.split() else o for o in ops]
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", line)
+            if m:
+                n = int(m.group(1))
+                if n == 0:
+                    out = []
+                elif not any(r[3] for r in out) and n < len(out):
+                    out = out[len(out) - n:]
+            continue
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            out = []
+            continue
+        touched = set(r for o in ops for r in _regs(o))
+        for rec in out:
+            hit = touched & rec[2]
+            if hit:
+                bad.append(f"v{sorted(hit)[0]} touched by `{line}` (line {i + 1}) while `{rec[1].strip()}` (line {rec[0] + 1}) may be in flight")
+                rec[2] -= hit
+        if op.startswith("ds_"):
+            returns = op.startswith(("ds_read", "ds_bpermute", "ds_permute", "ds_swizzle", "ds_consume", "ds_append")) or "_rtn" in op
+            dst = set(_regs(ops[0])) if returns and ops else set()
+            seen += bool(dst)
+            out.append([i, raw, dst, False])
+        elif op.startswith(("s_load", "s_buffer_load", "s_memtime", "s_memrealtime", "s_sendmsg", "s_dcache")):
+            out.append([i, raw, set(), True])
+    return bad, seen
+
+
+def test_lds_scanner_sees_a_fragment_read_used_behind_a_wait_that_does_not_cover_it():
+    ok = "ds_read_b128 v[0:3], v9\nds_read_b128 v[4:7], v9 offset:16\ns_waitcnt lgkmcnt(1)\nv_add_f32 v8, v0, v1\ns_waitcnt lgkmcnt(0)\nv_add_f32 v8, v4, v8\n"
+    assert _scan_lds_reads_in_flight(ok) == ([], 2)
+    early = ok.replace("lgkmcnt(1)\nv_add_f32 v8, v0, v1", "lgkmcnt(1)\nv_add_f32 v8, v4, v1")
+    assert len(_scan_lds_reads_in_flight(early)[0]) == 1
+    # a scalar load in between (as an asm statement would issue it, unknown to the compiler): the counted wait proves nothing
+    smem = ok.replace("ds_read_b128 v[4:7]", "s_load_dwordx2 s[0:1], s[2:3], 0x0\nds_read_b128 v[4:7]").replace("lgkmcnt(1)", "lgkmcnt(2)")
+    assert len(_scan_lds_reads_in_flight(smem)[0]) == 1
+    lane = "v_readfirstlane_b32 s4, v0\nv_readlane_b32 s5, v1, s4\n"
+    assert len(_scan_valu_sgpr_to_vmem(lane)[0]) == 1 and _scan_valu_sgpr_to_vmem(lane.replace("\nv_readlane", "\ns_nop 3\nv_readlane"))[0] == []
 
 
 def test_scanner_sees_a_restored_pointer_read_too_early():
@@ -297,13 +368,24 @@ def test_no_vector_memory_instruction_of_the_built_library_reads_a_freshly_valu_
     res = type("R", (), {"stdout": text})
     kernels = re.split(r"\n(?=[0-9a-f]{16} <[^>]+>:\n)", res.stdout)[1:]
     assert len(kernels) >= 50, len(kernels)
-    total, names = 0, []
+    total, names, lds_total, vm_total = 0, [], 0, 0
     for k in kernels:
         name = re.match(r"[0-9a-f]{16} <([^>]+)>:", k).group(1)
-        bad, seen = _scan_valu_sgpr_to_vmem("\n".join(k.splitlines()[1:]))
+        body = "\n".join(re.sub(r"^\s*[0-9a-f]+:\s*", "", l) if False else l for l in k.splitlines()[1:])
+        bad, seen = _scan_valu_sgpr_to_vmem(body)
         assert not bad, name + "\n" + "\n".join(bad[:8])
         total += seen
         names.append(name)
+        # round 5: every kernel's LDS reads and VGPR-destination vector loads against the waits that cover them
+        bad, seen = _scan_lds_reads_in_flight(body)
+        assert not bad, name + "\n" + "\n".join(bad[:8])
+        lds_total += seen
+        if "siren_trunk_f16x3w_kernel" not in name:   # (its slot bodies are not laid out in execution order: checked from its own TU above)
+            bad, seen = _scan_loads_in_flight(body)
+            assert not bad, name + "\n" + "\n".join(bad[:8])
+            vm_total += seen
+    assert lds_total > 2000 and vm_total > 2000, (lds_total, vm_total)
+    assert sum("latent_mods_f16x3_kernel" in nm for nm in names) >= 8 and sum("encoder_conv_f16x3_kernel" in nm for nm in names) == 2
     assert sum("siren_trunk_x1w_kernel" in nm for nm in names) == 8 and total > 5000, (len(names), total)
 
 

@@ -315,6 +315,46 @@ def test_f16x3_scale_folding_over_weight_and_modulation_magnitudes(wscale, mlo, 
     assert e64 <= 1e-4 or e32 > 2e-5, (e64, e32)   # the gate, unless fp32 itself is already that far from fp64 here
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_f16x3_log_uniform_modulations_within_a_row_and_outlier_weight_rows(seed):
+    """The shape in which ONE power-of-two scale per hidden layer helps least (round-4 review): modulations drawn log-uniformly
+    from 1e-6 ... 1e3 WITHIN each row -- tiny and large side by side, so no single exponent suits a row -- and hidden weight
+    matrices with a few rows 100 x larger than the rest (the layer's scale is set by them; every other row sits 100 x deeper in
+    fp16's subnormal range).  Gate as test_f16x3_scale_folding_...: within the larger of 10 x the distance of the reference's
+    own fp32 arithmetic (modulated_siren.py:215-233) from fp64, and 2e-5; rows that leave the fp16 domain are repaired to the
+    exact-fp32 trunk's bits by the conditional launch, so the output is finite either way."""
+    L, B = 5, 48
+    rng = np.random.default_rng(100 + seed)
+    sd = syn.make_state_dict(seed=11 + seed, with_encoder=False)
+    sd = {k: v for k, v in sd.items() if not k.startswith("modulator")}
+    for l in range(1, L):
+        w = sd[f"net.layers.{l}.weight"].copy()
+        w[rng.choice(256, 4, replace=False)] *= np.float32(100.0)
+        sd[f"net.layers.{l}.weight"] = w
+    kw = dict(dim_in=2, dim_hidden=256, dim_out=1, num_layers=L, latent_dim=256, w0=1.0, w0_initial=30.0, use_bias=True, dropout=0.1,
+              modulate=True, encoder_type="custom", encoder_path=None, outer_patch_size=32, inner_patch_size=16, siren_patch_size=24,
+              device="cuda", activation="sine")
+    m, f = ModulatedSiren(**kw, precision="f16x3"), ModulatedSiren(**kw, precision="fp32")
+    for mm in (m, f):
+        mm.load_state_dict(sd, strict=False)
+        mm.to("cuda")
+    for hi in (0.0, 3.0):   # 1e-6 ... 1 (inside the fp16 domain) and 1e-6 ... 1e3 (rows beyond 65 504 / 2^a: repaired)
+        mods = (10.0 ** rng.uniform(-6.0, hi, (L, B, 256))).astype(np.float32)
+        out = m.forward_mods(mods).reshape(B, -1)
+        ref64 = orc.siren_forward(sd, mods, num_layers=L, dtype=np.float64)
+        ref32 = orc.siren_forward(sd, mods, num_layers=L)
+        assert np.isfinite(out).all()
+        scale = max(np.abs(ref64).max(), 1e-30)
+        e64, e32 = np.abs(out - ref64).max() / scale, np.abs(ref32 - ref64).max() / scale
+        assert e64 <= max(10 * e32, 2e-5), (hi, e64, e32)
+        # per row as well: a row of small outputs is not hidden behind the batch's largest
+        rows = np.abs(out - ref64).max(axis=1) / np.maximum(np.abs(ref64).max(axis=1), 1e-30)
+        rows32 = np.abs(ref32 - ref64).max(axis=1) / np.maximum(np.abs(ref64).max(axis=1), 1e-30)
+        assert (rows <= np.maximum(10 * rows32, 5e-5)).all(), (hi, rows.max(), rows32.max())
+        exact = f.forward_mods(mods).reshape(B, -1)
+        assert np.abs(out - exact).max() / scale <= max(10 * e32, 2e-5)
+
+
 def test_f16x3_full_forward_matches_fp32_path():
     sd = syn.make_state_dict(seed=7, trained_like=True)
     m32 = make_model(sd, precision="fp32")
