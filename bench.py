@@ -77,6 +77,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--check", action="store_true", help="also verify one batch against the oracle")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="self-launched ranks: wall limit of the whole job")
+    ap.add_argument("--numa-pin", action="store_true",
+                    help="pin each rank to the CPUs of its GPU's NUMA node before it touches HIP (mri_inr_amd/launch.py; off by default, "
+                         "reported in config.ranks[]; untested on a multi-socket node)")
     ap.add_argument("--scaling-selftest", action="store_true",
                     help="run the N = 1 measurement twice -- plainly, and through the launcher path (one rank with "
                          "RANK / WORLD_SIZE=1 / MASTER_* set, what a scaling sweep's N = 1 point goes through) -- and fail "
@@ -243,6 +246,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py without a launcher (it starts its "
                          f"own ranks) or make the launcher's --nproc-per-node match")
 
+    # optional: CPU affinity by the GPU's NUMA node -- BEFORE anything starts the HIP runtime's threads
+    numa = launch.pin_rank(local_rank) if args.numa_pin else None
+
     deep = args.model == "deep_residual"
     if args.precision is None:
         args.precision = "bf16" if deep else "f16x3"
@@ -331,17 +337,21 @@ def main():
         pci = [int(dom, 16), int(bus, 16), int(devfn.split(".")[0], 16), int(devfn.split(".")[1], 16)]
     except Exception:  # noqa: BLE001
         pci = [-1, -1, -1, -1]
-    NF = 9
+    NF = 11
     table = [-1.0] * (world * NF)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else -1
     table[rank * NF:(rank + 1) * NF] = [float(dev)] + [float(x) for x in pci] + \
-        [float(info0["compute_units"]), float(info0["clock_mhz"]), float(info0["hbm_bytes"] >> 20), float(comm_rank)]
+        [float(info0["compute_units"]), float(info0["clock_mhz"]), float(info0["hbm_bytes"] >> 20), float(comm_rank),
+         float(numa["numa_node"]) if numa else -1.0, float(ncpu)]
     table = group.max_array(table)
     ranks_info = []
     for r in range(world):
         row = table[r * NF:(r + 1) * NF]
         ranks_info.append({"rank": r, "device": int(row[0]),
                            "pci_bus_id": "%04x:%02x:%02x.%x" % tuple(int(x) for x in row[1:5]) if row[1] >= 0 else None,
-                           "compute_units": int(row[5]), "clock_mhz": int(row[6]), "hbm_mib": int(row[7]), "comm_rank": int(row[8])})
+                           "compute_units": int(row[5]), "clock_mhz": int(row[6]), "hbm_mib": int(row[7]), "comm_rank": int(row[8]),
+                           # --numa-pin: the NUMA node the rank was pinned to (null: not asked for, or unknown) and the CPUs it may run on
+                           "numa_node": int(row[9]) if row[9] >= 0 else None, "cpus_allowed": int(row[10])})
     if world > 1 and len({(x["pci_bus_id"]) for x in ranks_info}) < world and backend != "gloo" and not os.environ.get("MSIREN_BENCH_ALLOW_SHARED"):
         raise SystemExit(f"[rank {rank}] two ranks report the same PCI device: {ranks_info}")
 

@@ -198,3 +198,112 @@ def exchange_from_rank0(payload: bytes | None, *, key: str = "msiren_comm_id", t
             return payload
         return bytes(store.get(run_key))
     return _exchange_socket(payload, rank, world, addr, port, timeout)
+
+
+# ---- optional: rank -> CPU affinity by the GPU's NUMA node (off by default) -------------------------------------------------
+# One process per GPU; on a two-socket node a rank whose host threads (launches, pageable copies, the rendezvous) run on the
+# other socket pays a cross-socket hop for every doorbell and every staged copy.  `bench.py --numa-pin` pins each rank, BEFORE it
+# touches HIP (threads the runtime starts later inherit the mask), to the CPUs of the NUMA node its GPU hangs off:
+#   PCI bus id of local rank r  <-  MSIREN_RANK_PCI_BUSIDS (comma-separated, by local rank) or `rocm-smi --showbus --json`
+#   NUMA node                   <-  /sys/bus/pci/devices/<busid>/numa_node        (-1: unknown -> no pinning)
+#   its CPUs                    <-  /sys/devices/system/node/node<N>/cpulist, intersected with the mask the process already has
+# Nothing here imports torch or the HIP library; the sysfs root and the smi runner are parameters so that the CPU tests can
+# hand in a fake tree.  No scaling run on a multi-GPU node has exercised this: it is reported in config.ranks[], not claimed.
+
+def parse_cpulist(text: str) -> list[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def format_cpulist(cpus) -> str:
+    cpus = sorted(set(cpus))
+    out, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def gpu_busids_from_smi(runner=None) -> list[str]:
+    """PCI bus ids of the GPUs in device order, from `rocm-smi --showbus --json` (a subprocess: this process stays off the GPU).
+    Empty list when the tool is missing or its output is not understood."""
+    import json
+    import re
+
+    runner = runner or (lambda: subprocess.run(["rocm-smi", "--showbus", "--json"], capture_output=True, text=True, timeout=30).stdout)
+    try:
+        data = json.loads(runner())
+    except Exception:  # noqa: BLE001 -- optional feature: any failure means "unknown"
+        return []
+    ids = []
+    for key in sorted((k for k in data if re.fullmatch(r"card\d+", k)), key=lambda k: int(k[4:])):
+        val = next((v for kk, v in data[key].items() if "bus" in kk.lower()), None)
+        if not isinstance(val, str) or not re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-7]", val.strip()):
+            return []
+        ids.append(val.strip().lower())
+    return ids
+
+
+def numa_node_of(busid: str, sysfs: str = "/sys") -> int:
+    try:
+        with open(os.path.join(sysfs, "bus", "pci", "devices", busid.lower(), "numa_node")) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def cpus_of_node(node: int, sysfs: str = "/sys") -> list[int]:
+    try:
+        with open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")) as f:
+            return parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return []
+
+
+def rank_affinity(local_rank: int, *, busids=None, sysfs: str = "/sys", allowed=None, env=None) -> dict | None:
+    """{'pci_bus_id', 'numa_node', 'cpus'} for a local rank, or None when anything is unknown (then nothing is pinned)."""
+    env = os.environ if env is None else env
+    if busids is None:
+        listed = [b.strip() for b in env.get("MSIREN_RANK_PCI_BUSIDS", "").split(",") if b.strip()]
+        busids = listed or gpu_busids_from_smi()
+    vis = env.get("HIP_VISIBLE_DEVICES") or env.get("ROCR_VISIBLE_DEVICES")
+    if vis and all(t.strip().isdigit() for t in vis.split(",")):   # the runtime renumbers the visible devices
+        order = [int(t) for t in vis.split(",")]
+        busids = [busids[i] for i in order if i < len(busids)]
+    if not 0 <= local_rank < len(busids):
+        return None
+    node = numa_node_of(busids[local_rank], sysfs)
+    if node < 0:
+        return None
+    cpus = set(cpus_of_node(node, sysfs))
+    if allowed is None and hasattr(os, "sched_getaffinity"):
+        allowed = os.sched_getaffinity(0)
+    if allowed is not None:
+        cpus &= set(allowed)
+    if not cpus:
+        return None
+    return {"pci_bus_id": busids[local_rank], "numa_node": node, "cpus": format_cpulist(cpus)}
+
+
+def pin_rank(local_rank: int, *, setter=None, **kw) -> dict | None:
+    """Pin the calling process to its GPU's NUMA node (call BEFORE the HIP runtime starts its threads).  Returns what was
+    applied (for config.ranks[]) or None."""
+    info = rank_affinity(local_rank, **kw)
+    if info is None:
+        return None
+    setter = setter or (lambda cpus: os.sched_setaffinity(0, cpus))
+    try:
+        setter(set(parse_cpulist(info["cpus"])))
+    except OSError:
+        return None
+    return info
