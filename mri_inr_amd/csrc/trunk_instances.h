@@ -61,6 +61,7 @@ extern template __global__ void latent_mods_f16x3_kernel<2, 2, 8, 3>(EmTailParam
 extern template __global__ void latent_mods_f16x3_kernel<2, 2, 4, 1>(EmTailParams);
 extern template __global__ void latent_mods_f16x3_kernel<2, 2, 4, 2>(EmTailParams);
 extern template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 3>(EmTailParams);
+extern template __global__ void latent_mods_f16x3_kernel<4, 1, 8, 3>(EmTailParams);
 extern template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 1>(EmTailParams);
 extern template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 2>(EmTailParams);
 extern template __global__ void encoder_conv_f16x3_kernel<0>(EncoderParams, const float*, em_u4*, float*);
