@@ -64,6 +64,12 @@ struct EmTailParams {
     int wave_stride;         // em_u4 per wave stream
     int zp_start;            // k-step at which the z stage begins in a wave's stream (entry point when the latent is given)
     const int* count;        // optional: number of rows to process, on the device (<= B)
+    // Latency sizes only: the grid carries `pf_blocks` workgroups behind the row blocks that do nothing but pull the weight stream into
+    // their XCD's L2 -- between two calls the trunk's traffic evicts it (rocprofv3: every XCD fetches the 2.9 MB again, 29 MB per
+    // launch), and ONE workgroup streams from the Infinity Cache at 96 GB/s where it gets 127 GB/s from L2 (tools/l2_stream_probe.hip).
+    // Workgroup e of them takes slice e / 8 of eight (consecutive workgroup ids go to consecutive XCDs), in consumption order.
+    int row_blocks, pf_blocks;
+    unsigned pf_lines;       // 1 KB lines (64 lanes x 16 B) per slice
 };
 
 // max -> power-of-two scale of a row: m * 2^s in [2^13, 2^14); s clamped so that 2^s and 2^-s are normal numbers
@@ -127,6 +133,22 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nrows = p.count ? *p.count : p.B;
     const int rb = blockIdx.x, r0 = rb * EM_ROWS;
+    if (p.pf_blocks && rb >= p.row_blocks) {  // workgroup-uniform
+        const em_u4* src = p.wstream + (size_t)((rb - p.row_blocks) >> 3) * p.pf_lines * 64 + lane;
+        unsigned acc_ = 0;
+        for (unsigned i = wave; i < p.pf_lines; i += 32) {  // 8 lines per wave in flight; plain loads: the compiler counts them
+            em_u4 v[8];
+#pragma unroll
+            for (unsigned u = 0; u < 8; ++u) {
+                const unsigned j = i + 4 * u < p.pf_lines ? i + 4 * u : i;
+                v[u] = src[(size_t)j * 64];
+            }
+#pragma unroll
+            for (unsigned u = 0; u < 8; ++u) acc_ ^= v[u][0];
+        }
+        asm volatile("; the prefetched lines have arrived" ::"v"(acc_));
+        return;
+    }
     if (r0 >= nrows) return;  // workgroup-uniform
     // (beside a trunk wave on its SIMD this wave issues little -- a vector load here, six MFMAs there -- but each of its
     //  instructions is on the critical path of a 25-workgroup launch: let it win the arbitration)

@@ -155,6 +155,7 @@ struct msiren_ctx {
     float em_winv_c3 = 1.f, em_winv_fc = 1.f, em_winv_z[64] = {0}, em_winv_h[64] = {0};
     int em_wave_stride = 0, em_zp_start = 0;
     bool em_enc = false, em_mod = false;  // which halves of the stream are packed (the checkpoint's key set decides)
+    int em_prefetch = 1;           // MSIREN_EM_PREFETCH=0: no L2-prefetch workgroups in the prologue's grid (A/B knob)
     int em_depth = 0;              // MSIREN_EM_DEPTH=2|4|8: force the weight-ring depth of the split-fp16 prologue (A/B knob)
     int ws_two = 0;                // MSIREN_WS_TWO=1: the weight-stationary trunk on two-stream handles as well (experiment)
     int em_enabled = 1;            // MSIREN_PROLOGUE_F16X3=0: the exact-fp32 launches per layer (A/B knob, read at create)
@@ -1272,8 +1273,14 @@ int launch_prologue_f16x3_t(msiren_ctx* h, const float* tiles_dev, const float* 
     const bool alone = (h->nstreams == 1 || h->solo) && !h->overlap && !h->em_beside;
     int depth = alone ? (nblk <= (int64_t)h->num_cus ? 8 : 4) : 2;
     if (h->em_depth) depth = h->em_depth;
+    // latency sizes of the H = 256 model: 64 more workgroups (8 per XCD) that only pull the 2.9 MB weight stream into the L2s (EmTailParams)
+    p.row_blocks = (int)nblk;
+    if (NPH == 2 && h->em_prefetch && alone && nblk <= 64 && tiles_dev && mods_dev) {
+        p.pf_blocks = 64;
+        p.pf_lines = (unsigned)(((size_t)h->em_wave_stride * 4 * 16 / 8 + 1023) / 1024);
+    }
     // (the halves alone -- model.encoder(tiles), model.modulator(z) -- have the ring of 4 only)
-    const dim3 grid((unsigned)nblk), wg(256);
+    const dim3 grid((unsigned)(nblk + p.pf_blocks)), wg(256);
     hipStream_t st = c.s;
     if (tiles_dev && !mods_dev) hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 4, 1>), grid, wg, lds, st, p);
     else if (!tiles_dev) hipLaunchKernelGGL((msiren::latent_mods_f16x3_kernel<NPH, NPZ, 4, 2>), grid, wg, lds, st, p);
@@ -1680,6 +1687,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_SPLIT_PCT")) h->split_pct = std::max(1, std::min(90, std::atoi(e)));
     if (const char* e = std::getenv("MSIREN_TRACE_HOST")) h->trace_host = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_PROLOGUE_F16X3")) h->em_enabled = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_EM_PREFETCH")) h->em_prefetch = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_EM_DEPTH")) h->em_depth = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_CONV_MFMA")) h->em_conv_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_WS_TWO")) h->ws_two = std::atoi(e);
