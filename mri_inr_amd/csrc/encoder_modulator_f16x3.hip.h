@@ -476,13 +476,12 @@ static_assert(em_tail_lds_bytes<2, 2>() <= 34 * 1024, "the H = Z = 256 instance 
 //   16 (w & 1) + 4 q + r at positions 16 (2 (w >> 1) + t) + n  (j = 4 t + r).
 template <int VARIANT>
 __global__ __launch_bounds__(256, 5) void encoder_conv_f16x3_kernel(EncoderParams p, const float* __restrict__ tiles, em_u4* __restrict__ feat,
-                                                                      float* __restrict__ feat_inv, int row0) {
+                                                                      float* __restrict__ feat_inv) {
     __shared__ float t0[33 * 33];
     __shared__ float wmax[8];
     const int tid = threadIdx.x;
-    // (row0: a host call uploads its tiles in pieces and launches this kernel per piece, rows [row0, row0 + gridDim.x) of the batch)
     if (p.plan && (int)blockIdx.x >= p.plan[0]) return;  // workgroup-uniform
-    const float* tile = tiles + (size_t)(p.plan ? p.plan[2 + blockIdx.x] : row0 + (int)blockIdx.x) * 1024;
+    const float* tile = tiles + (size_t)(p.plan ? p.plan[2 + blockIdx.x] : (int)blockIdx.x) * 1024;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     em_f4 o0, o1;  // the thread's eight features (before scale and split)
 
@@ -622,7 +621,7 @@ __global__ __launch_bounds__(256, 5) void encoder_conv_f16x3_kernel(EncoderParam
     em_row_scale(m, sc, inv);
     em_u4 hi, lo;
     em_split8(o0 * sc, o1 * sc, hi, lo);
-    const int row = row0 + (int)blockIdx.x, ks = 16 * wv + (lane >> 2), qq = lane & 3;
+    const int row = blockIdx.x, ks = 16 * wv + (lane >> 2), qq = lane & 3;
     em_u4* dst = feat + ((size_t)(row >> 4) * EM_C3_KSTEPS + ks) * 128 + qq * 16 + (row & 15);
     dst[0] = hi;
     dst[64] = lo;

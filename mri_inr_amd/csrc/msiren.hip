@@ -86,7 +86,6 @@ struct msiren_ctx {
     int trunk_force = 0;
     hipEvent_t trunk_after = nullptr;  // the next trunk launch waits for this event first (a pipelined host call: the weight-stationary
                                        // trunk of the last chunk behind the other stream's conditional launch, which cannot run beside it)
-    bool conv_done = false;  // the conv kernel of the call in flight has been launched already (streamed upload of a host call)
     bool no_split = false;   // a host call that pipelines itself: its chunks are not cut again by forward_tiles_split
     bool em_beside = false;  // the prologue being launched runs beside a trunk of this call (forward_tiles_split): shallow weight ring
     int64_t split_min = 3200;  // MSIREN_SPLIT_MIN: *_dev forward calls of at least this many tiles are cut in two (0 = never)
@@ -139,7 +138,6 @@ struct msiren_ctx {
     int cus_limit = 256;       // MSIREN_GRID: cap on the persistent grids
     int ring_force = 0;        // MSIREN_F16_RING: 3 / 4 forces the weight ring depth of the register-resident trunk
     int half_allowed = 1;      // MSIREN_F16_HALF=0: never use the half-unit instance
-    int host_up = 100;         // MSIREN_HOST_UP: tiles per upload piece of a host call (the conv kernel of a piece runs beside the next piece's copy; 0: one copy)
     int host_pipe_min = 800;   // MSIREN_HOST_PIPE_MIN: tiles from which a host call pipelines itself (one slice: one chunk is as fast, profiles/r5)
     int host_first = 112, host_piece = 400;  // MSIREN_HOST_FIRST / MSIREN_HOST_PIECE: tiles in the first / the further chunks of a pipelined host call
     int host_chunks = 0;       // MSIREN_HOST_CHUNKS: chunks a synchronous host call cuts itself into (0 = default)
@@ -1232,21 +1230,6 @@ int launch_linear(msiren_ctx* h, const msiren::ModulatorMfmaParams& mp) {
 // encoder tail + Modulator in ONE launch (plus the conv kernel in front when tiles are given): split-fp16 arithmetic,
 // a row block of 16 patches per workgroup through every layer (encoder_modulator_f16x3.hip.h).
 //   tiles -> [z_out] -> [mods]     (tiles_dev given)        z_in -> mods     (tiles_dev null)
-// conv1 + conv2 of rows [row0, row0 + n) of a batch of B tiles -> conv3's B images (the feature buffer is laid out for all B rows)
-int launch_conv_f16x3(msiren_ctx* h, const float* tiles_dev, int64_t B, int64_t row0, int64_t n) {
-    auto& c = h->sc[h->cur];
-    const int64_t rows16 = (B + msiren::EM_ROWS - 1) / msiren::EM_ROWS * msiren::EM_ROWS;
-    int rc = ensure(h, c.feat, (size_t)rows16 * 2048 * 4 + (size_t)rows16 * 4 + msiren::EM_MAX_DEPTH * 2048);  // (+ padding: conv3's B ring prefetches past the end)
-    if (rc) return rc;
-    if (n <= 0) return 0;
-    h->enc.plan = h->plan;
-    float* const finv = (float*)((char*)c.feat.p + (size_t)rows16 * 2048 * 4 + msiren::EM_MAX_DEPTH * 2048);
-    if (h->em_conv_mfma) hipLaunchKernelGGL(msiren::encoder_conv_f16x3_kernel<1>, dim3((unsigned)n), dim3(256), 0, c.s, h->enc, tiles_dev, (msiren::em_u4*)c.feat.p, finv, (int)row0);
-    else hipLaunchKernelGGL(msiren::encoder_conv_f16x3_kernel<0>, dim3((unsigned)n), dim3(256), 0, c.s, h->enc, tiles_dev, (msiren::em_u4*)c.feat.p, finv, (int)row0);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
 template <int NPH, int NPZ>
 int launch_prologue_f16x3_t(msiren_ctx* h, const float* tiles_dev, const float* z_in, int64_t B, float* z_out, float* mods_dev) {
     auto& c = h->sc[h->cur];
@@ -1255,10 +1238,14 @@ int launch_prologue_f16x3_t(msiren_ctx* h, const float* tiles_dev, const float* 
     int rc;
     msiren::EmTailParams p{};
     if (tiles_dev) {
-        // (conv_done: a host call has launched the conv kernel piece by piece behind its uploads already)
-        if (!h->conv_done && (rc = launch_conv_f16x3(h, tiles_dev, B, 0, B))) return rc;
+        if ((rc = ensure(h, c.feat, (size_t)rows16 * 2048 * 4 + (size_t)rows16 * 4 + msiren::EM_MAX_DEPTH * 2048))) return rc;  // (+ padding: conv3's B ring prefetches past the end)
         p.feat = (const msiren::em_u4*)c.feat.p;
         p.feat_inv = (const float*)((const char*)c.feat.p + (size_t)rows16 * 2048 * 4 + msiren::EM_MAX_DEPTH * 2048);
+        h->enc.plan = h->plan;
+        float* const finv = (float*)((char*)c.feat.p + (size_t)rows16 * 2048 * 4 + msiren::EM_MAX_DEPTH * 2048);
+        if (h->em_conv_mfma) hipLaunchKernelGGL(msiren::encoder_conv_f16x3_kernel<1>, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, (msiren::em_u4*)c.feat.p, finv);
+        else hipLaunchKernelGGL(msiren::encoder_conv_f16x3_kernel<0>, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, (msiren::em_u4*)c.feat.p, finv);
+        HIPCHK(hipGetLastError());
     }
     if (mods_dev) {
         if ((rc = ensure(h, c.cscratch, (size_t)nblk * std::max(1, h->L - 1) * NPH * 512 * 16))) return rc;
@@ -1685,7 +1672,6 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_GRID")) h->cus_limit = std::max(1, std::min(h->num_cus, std::atoi(e)));
     if (const char* e = std::getenv("MSIREN_F16_RING")) h->ring_force = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_F16_HALF")) h->half_allowed = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_HOST_UP")) h->host_up = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("MSIREN_HOST_PIPE_MIN")) h->host_pipe_min = std::max(128, std::atoi(e));
     if (const char* e = std::getenv("MSIREN_HOST_FIRST")) h->host_first = std::max(16, std::atoi(e));
     if (const char* e = std::getenv("MSIREN_HOST_PIECE")) h->host_piece = std::max(64, std::atoi(e));
@@ -1984,7 +1970,7 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     struct Restore {  // the launchers address the stream through h->cur, the trunk through h->trunk_force, the prologue's ring through h->em_beside
         msiren_ctx* h;
         int cur;
-        ~Restore() { h->cur = cur; h->trunk_force = 0; h->em_beside = false; h->overlap = false; h->no_split = false; h->trunk_after = nullptr; h->conv_done = false; }
+        ~Restore() { h->cur = cur; h->trunk_force = 0; h->em_beside = false; h->overlap = false; h->no_split = false; h->trunk_after = nullptr; }
     } restore{h, cur0};
     h->no_split = pipelined;
     auto download = [&](int k) {
@@ -2000,27 +1986,13 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
         h->trunk_force = c.trunk;
         h->em_beside = c.beside;
         float* d_t = (float*)h->ws_tiles.p + (size_t)c.lo * tile_elems;
-        // Streamed upload (round 5): a pageable copy blocks the host until it is done, and the first kernel reached the device ~20 us
-        // later still.  The chunk's tiles go up in pieces of `host_up` tiles, the conv kernel of a piece is launched behind its
-        // copy and runs while the next piece is copied; the one-launch encoder tail + Modulator and the trunk follow over the whole
-        // chunk (profiles/r5/04_host_call_pipelining.txt).
-        const bool streamed = h->host_up > 0 && c.n >= 2 * h->host_up && h->em_enc && h->em_mod && !h->plan && !use_split(h, c.n);
-        const int64_t piece = streamed ? h->host_up : c.n;
-        for (int64_t o = 0, m = 0; o < c.n && !rc; o += m) {
-            m = std::min<int64_t>(piece, c.n - o);
-            if (c.n - o - m < piece / 2) m = c.n - o;  // (no tiny last piece)
-            hipError_t e = hipMemcpyAsync(d_t + (size_t)o * tile_elems, tiles_host + (size_t)(c.lo + o) * tile_elems, (size_t)m * tile_elems * sizeof(float),
-                                          hipMemcpyHostToDevice, h->sc[c.stream].s);
-            if (e != hipSuccess) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(H2D): %s", hipGetErrorString(e));
-            if (streamed && !rc) rc = launch_conv_f16x3(h, d_t, c.n, o, m);
-        }
-        h->conv_done = streamed;
+        hipError_t e = hipMemcpyAsync(d_t, tiles_host + (size_t)c.lo * tile_elems, (size_t)c.n * tile_elems * sizeof(float), hipMemcpyHostToDevice, h->sc[c.stream].s);
+        if (e != hipSuccess) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(H2D): %s", hipGetErrorString(e));
         tr_h2d[k] = us();
         // (the weight-stationary trunk owns its CUs: queued beside the previous chunk's conditional exact-fp32 launch it would start first,
         //  and that launch -- and the download behind it -- would wait for it to end)
         if (pipelined && c.trunk == 2 && k >= 1 && !rc) h->trunk_after = h->sc[plan[k - 1].stream].ev_join;
         if (!rc) rc = forward_tiles_dev(h, d_t, c.n, (float*)h->ws_out.p + (size_t)c.lo * h->P);
-        h->conv_done = false;
         if (pipelined && !rc) {
             auto& sc = h->sc[c.stream];
             if (!sc.ev_join) { hipError_t e2 = hipEventCreateWithFlags(&sc.ev_join, hipEventDisableTiming); if (e2 != hipSuccess) rc = fail(MSIREN_E_HIP, "hipEventCreate: %s", hipGetErrorString(e2)); }

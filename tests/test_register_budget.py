@@ -25,8 +25,8 @@ template __global__ void msiren::siren_trunk_f16x3n_kernel<0, 3, 5>(msiren::Trun
 template __global__ void msiren::siren_trunk_f16x3n_kernel<1, 3, 5>(msiren::TrunkF16Params);
 template __global__ void msiren::linear_mfma_tile_kernel<2, 2>(msiren::ModulatorMfmaParams);
 template __global__ void msiren::latent_mods_f16x3_kernel<2, 2, 2, 3>(msiren::EmTailParams);
-template __global__ void msiren::encoder_conv_f16x3_kernel<0>(msiren::EncoderParams, const float*, msiren::em_u4*, float*, int);
-template __global__ void msiren::encoder_conv_f16x3_kernel<1>(msiren::EncoderParams, const float*, msiren::em_u4*, float*, int);
+template __global__ void msiren::encoder_conv_f16x3_kernel<0>(msiren::EncoderParams, const float*, msiren::em_u4*, float*);
+template __global__ void msiren::encoder_conv_f16x3_kernel<1>(msiren::EncoderParams, const float*, msiren::em_u4*, float*);
 template __global__ void msiren::siren_trunk_f32_cond_kernel<0>(msiren::TrunkParams);
 template __global__ void msiren::siren_trunk_f32_cond_kernel<1>(msiren::TrunkParams);
 """
