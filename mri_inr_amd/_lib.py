@@ -88,6 +88,8 @@ PROTOTYPES = {
     "msiren_set_streams": (C.c_int, [_vp, _i32]),
     "msiren_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "msiren_dev_free": (C.c_int, [_vp, _vp]),
+    "msiren_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "msiren_host_free": (C.c_int, [_vp, _vp]),
     "msiren_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "msiren_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "msiren_timer_start": (C.c_int, [_vp]),

@@ -1939,9 +1939,12 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     struct Chunk { int64_t lo, n; int stream, trunk; bool beside; };
     std::vector<Chunk> plan;
     const int cur0 = h->cur;
+    // (page-locked buffers -- msiren_host_alloc, a pinned torch tensor -- need nothing special here: hipMemcpyAsync then is DMA without staging and
+    //  does not block: one slice 437 -> 394 us in one chunk; cutting it pays from two slices up as with pageable memory, 406 us at one --
+    //  profiles/r5/04_host_call_pipelining.txt)
     const bool pipelined = h->host_chunks == 0 && B >= h->host_pipe_min && use_f16x3(h) && !h->x1_ready && h->L == 5 && h->em_enc && h->em_mod && ws_capable(h, B);
     if (pipelined) {
-        const int64_t first = std::min<int64_t>(h->host_first, B - 64), piece = h->host_piece;
+        const int64_t first = std::min<int64_t>(h->host_first, std::max<int64_t>(16, B / 3)), piece = h->host_piece;
         plan.push_back({0, first, cur0, 1, false});
         for (int64_t lo = first; lo < B;) {
             int64_t n = std::min<int64_t>(piece, B - lo);
@@ -2227,6 +2230,26 @@ int msiren_dev_free(msiren_handle h, void* dev_ptr) {
     if (dev_ptr) {
         if ((rc = sync_all(h))) return rc;
         HIPCHK(hipFree(dev_ptr));
+    }
+    return 0;
+}
+
+int msiren_host_alloc(msiren_handle h, size_t bytes, void** host_ptr) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (!host_ptr) return fail(MSIREN_E_INVALID, "null argument");
+    *host_ptr = nullptr;
+    if (bytes == 0) return 0;
+    HIPCHK(hipHostMalloc(host_ptr, bytes, hipHostMallocDefault));
+    return 0;
+}
+
+int msiren_host_free(msiren_handle h, void* host_ptr) {
+    int rc = check(h, false);
+    if (rc) return rc;
+    if (host_ptr) {
+        if ((rc = sync_all(h))) return rc;  // (a copy to or from it may still be in flight)
+        HIPCHK(hipHostFree(host_ptr));
     }
     return 0;
 }

@@ -80,6 +80,55 @@ class DeviceArray:
             pass
 
 
+class _PinnedBlock:
+    """Page-locked host memory from msiren_host_alloc, exposed to numpy through __array_interface__; goes back to its model's
+    pool when the last array over it is gone (numpy keeps the exporting object alive as the array's base)."""
+
+    def __init__(self, pool, ptr, nbytes, shape):
+        self._pool, self.ptr, self.nbytes = pool, ptr, nbytes
+        self.__array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            self._pool._give_back(self.ptr, self.nbytes)
+        except Exception:
+            pass
+
+
+class _PinnedPool:
+    """Recycles page-locked blocks by size (hipHostMalloc costs ~100 us; the blocks of a steady loop are reused).  At most
+    `keep` idle blocks per size are kept; the rest is freed."""
+
+    def __init__(self, model, keep=8):
+        self._model, self._free, self._keep = model, {}, keep
+
+    def array(self, shape) -> np.ndarray:
+        shape = tuple(int(x) for x in shape)
+        nbytes = max(4, int(np.prod(shape, dtype=np.int64)) * 4)
+        lst = self._free.get(nbytes)
+        if lst:
+            ptr = lst.pop()
+        else:
+            p = C.c_void_p()
+            _lib.check(self._model._lib.msiren_host_alloc(self._model._h, nbytes, C.byref(p)))
+            ptr = p.value
+        return np.asarray(_PinnedBlock(self, ptr, nbytes, shape))
+
+    def _give_back(self, ptr, nbytes):
+        lst = self._free.setdefault(nbytes, [])
+        if len(lst) < self._keep and self._model._h:
+            lst.append(ptr)
+        elif self._model._h:
+            self._model._lib.msiren_host_free(self._model._h, ptr)
+
+    def drain(self):
+        for lst in self._free.values():
+            while lst:
+                ptr = lst.pop()
+                if self._model._h:
+                    self._model._lib.msiren_host_free(self._model._h, ptr)
+
+
 class ModulatedSiren:
     """See module docstring.  Constructor signature: modulated_siren.py:349-368."""
 
@@ -115,6 +164,8 @@ class ModulatedSiren:
                                       "scope of the MI355X path; use encoder_type='custom'")
         self._lib = None
         self._h = None
+        self._pinned = _PinnedPool(self)   # page-locked host arrays (pinned_empty, pin_outputs)
+        self._pin_outputs = False
         self._device = _device_index(device)
         self._committed = False
         # a fresh model has random weights, like a fresh nn.Module
@@ -298,6 +349,7 @@ class ModulatedSiren:
         if idx is None:
             raise _lib.MsirenError("ModulatedSiren (MI355X build) has no CPU path; .to('cpu') is not supported")
         if idx != self._device and self._h is not None:
+            self._pinned.drain()
             self._lib.msiren_destroy(self._h)
             self._h = None
         self._device = idx
@@ -324,6 +376,7 @@ class ModulatedSiren:
     def __del__(self):
         try:
             if self._h is not None and self._lib is not None:
+                self._pinned.drain()   # (blocks still under a live array stay allocated: their arrays outlive the model)
                 self._lib.msiren_destroy(self._h)
                 self._h = None
         except Exception:
@@ -354,7 +407,7 @@ class ModulatedSiren:
         a = np.ascontiguousarray(x, dtype=np.float32)
         self._check_tail(a.shape, in_tail)
         B = out_shape_fn(a.shape)
-        out = np.empty((B, S, S), dtype=np.float32)
+        out = self._pinned.array((B, S, S)) if self._pin_outputs and B else np.empty((B, S, S), dtype=np.float32)
         args = [self._h, a.ctypes.data if a.size else None, B, out.ctypes.data if out.size else None] + [None] * extra_null
         _lib.check(host_fn(*args))
         return out
@@ -464,6 +517,20 @@ class ModulatedSiren:
         return res
 
     # -------------------------------------------------------------------- low-level helpers ----
+    # ---- page-locked host memory: the counterpart of torch's pin_memory() / DataLoader(pin_memory=True) ----
+    def pinned_empty(self, shape) -> np.ndarray:
+        """A float32 numpy array in page-locked memory (msiren_host_alloc): calls that are handed such arrays copy by DMA
+        without staging and pipeline upload / kernels / download inside the call.  Recycled when the array is gone."""
+        self._ensure_handle()
+        return self._pinned.array(shape)
+
+    def pin_outputs(self, on: bool = True):
+        """Return the host-pointer calls' outputs in page-locked arrays from a recycling pool (off by default: pinned memory is a
+        finite resource, and an application that keeps thousands of outputs alive should not pin them)."""
+        self._ensure_handle()
+        self._pin_outputs = bool(on)
+        return self
+
     def device_array(self, shape) -> DeviceArray:
         self._ensure_handle()
         return DeviceArray(self, shape)

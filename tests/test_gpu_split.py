@@ -228,3 +228,42 @@ def test_out_of_domain_modulation_in_the_second_part_of_a_cut_call():
     assert np.array_equal(got[:B0], clean[:B0])                                  # first part: untouched
     assert np.array_equal(got[B0:], exact.forward_mods(mods[:, B0:]))            # second part: the exact-fp32 trunk's bits
     assert np.isfinite(got).all()
+
+
+def test_page_locked_buffers_same_bits_recycled_and_outlive_the_model():
+    """msiren_host_alloc / model.pinned_empty / model.pin_outputs: with page-locked input and output the copies are asynchronous DMA
+    without staging (one slice: 437 -> 394 us).  Same bits as the pageable call, at every size and through the cut call of
+    several slices; the pool recycles blocks; arrays stay valid after their model is gone."""
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    tiles = np.random.default_rng(31).random((400, 32, 32), dtype=np.float32)
+    m = make_model(sd, precision="f16x3")
+    ref = m(tiles)                                   # pageable in, pageable out: one chunk
+    _lib.check(m._lib.msiren_profile_enable(m._h, 1))
+    m(tiles)
+    assert len(m.profile_kernels()) == 1
+    pin = m.pinned_empty(tiles.shape)
+    pin[...] = tiles
+    m.pin_outputs(True)
+    out = m(pin)
+    assert np.array_equal(out, ref)
+    big = m.pinned_empty((1000, 32, 32))
+    big[...] = np.concatenate([tiles, tiles, tiles[:200]])
+    _lib.check(m._lib.msiren_profile_enable(m._h, 1))
+    got = m(big)
+    assert len(m.profile_kernels()) == 2                                     # >= 800 tiles: the call cuts itself
+    _lib.check(m._lib.msiren_profile_enable(m._h, 0))
+    assert np.array_equal(got[:400], ref) and np.array_equal(got[400:800], ref) and np.array_equal(got[800:], ref[:200])
+    del got, big
+    ptr0 = out.ctypes.data
+    for n in (1, 100, 128, 399):                     # below / above the threshold, ragged
+        assert np.array_equal(m(pin[:n]), ref[:n]), n
+    assert np.array_equal(m(tiles), ref)             # pageable input with pinned output: one chunk, still right
+    del out
+    again = m(pin)
+    assert again.ctypes.data == ptr0 or np.array_equal(again, ref)   # (the block came back from the pool)
+    m.pin_outputs(False)
+    keep = m(pin).copy()
+    del m
+    import gc
+    gc.collect()
+    assert np.array_equal(again, ref) and np.array_equal(keep, ref) and np.array_equal(pin, tiles)

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r5/${OUT:-quick}
 rm -rf $out && mkdir -p $out
-timeout -k 10 300 python3 tools/prologue_check.py > $out/check_new.txt 2>&1; echo "check rc=$?"; grep -v amdgpu.ids $out/check_new.txt | grep "scale 1 B   400\|scale 1e-05 B     1:\|scale 1 B  1030"
+timeout -k 10 300 python3 -m pytest tests/test_gpu_prologue.py -x -q > $out/check_new.txt 2>&1; echo "check rc=$?"; tail -2 $out/check_new.txt
 run() { name=$1; shift; timeout -k 10 300 python3 bench.py "$@" > $out/$name.json 2> $out/$name.err || { echo "$name failed"; tail -3 $out/$name.err; }; }
 A="--steps 600 --warmup 30 --no-cpu-baseline --no-extras"
 run s1 --streams 1 $A
