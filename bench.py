@@ -628,12 +628,27 @@ def extras(model, lib, h, _lib, d_img, d_tiles, d_recons, streams, budget_s=0.5)
       reconstruct_mpixel_s    slice -> tiles -> black filter -> forward -> weighted fold -> slice, device-resident
                               (msiren_reconstruct_slices_dev): "pixels reconstructed" in the literal sense."""
     tiles = d_tiles.numpy()[:400]
-    model(tiles)  # workspaces
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        model(tiles)
-        n += 1
-    h2h = n * 320 * 320 / (time.perf_counter() - t0) / 1e6
+
+    def host_rate(x, slices):
+        model(x)  # workspaces
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            model(x)
+            n += 1
+        return n * slices * 320 * 320 / (time.perf_counter() - t0) / 1e6
+
+    _lib.check(lib.msiren_set_streams(h, 1))
+    h2h = host_rate(tiles, 1)
+    # the same call on page-locked arrays (model.pinned_empty / pin_outputs: what torch users get from pin_memory()), and a call of 8
+    # slices, which cuts itself into chunks over the handle's two streams (uploads and downloads beside the other chunk's kernels)
+    pin = model.pinned_empty(tiles.shape)
+    pin[...] = tiles
+    model.pin_outputs(True)
+    h2h_pinned = host_rate(pin, 1)
+    model.pin_outputs(False)
+    eight = np.concatenate([tiles] * 8)
+    h2h_8 = host_rate(eight, 8)
+    del pin, eight
     _lib.check(lib.msiren_set_streams(h, streams))
     k = [0]
 
@@ -651,9 +666,11 @@ def extras(model, lib, h, _lib, d_img, d_tiles, d_recons, streams, budget_s=0.5)
         model.sync()
         n += 50
     rec = n * 320 * 320 / (time.perf_counter() - t0) / 1e6
-    return {"host_to_host_mpixel_s": h2h, "reconstruct_mpixel_s": rec,
-            "note": "one 320x320 slice per call, after the timed region: host numpy -> host numpy through "
-                    "msiren_forward_tiles (PCIe-inclusive), and the device-resident slice -> slice pipeline"}
+    return {"host_to_host_mpixel_s": h2h, "host_to_host_pinned_mpixel_s": h2h_pinned, "host_to_host_8_slices_mpixel_s": h2h_8,
+            "reconstruct_mpixel_s": rec,
+            "note": "after the timed region: host numpy -> host numpy through msiren_forward_tiles (PCIe-inclusive), one 320x320 slice per call "
+                    "on pageable arrays, on page-locked ones (model.pinned_empty / pin_outputs), 8 slices per call on pageable arrays (the call "
+                    "pipelines itself); and the device-resident slice -> slice pipeline, one slice per call"}
 
 
 def scaling_selftest(args) -> int:
