@@ -114,7 +114,7 @@ def traffic_bytes(kernel):
     instance, as {"bytes_per_launch", "source"}; None if there is none."""
     if not kernel:
         return None
-    for rnd in ("r4", "r3", "r2", "r1"):
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
         try:
             d = json.load(open(os.path.join(REPO, "profiles", rnd, "traffic.json")))
         except Exception:
