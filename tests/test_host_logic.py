@@ -152,6 +152,22 @@ def test_committed_bench_line_follows_the_contract():
                  "config5_deep_residual_bf16"):
         c = l4["extra"]["configs"][name]
         assert c["value"] > 0 and 0.1 < c["kernel_alone_frac"] < 1.0 and c["kernel"].startswith("siren_trunk_"), (name, c)
+    # round 5's line (profiles/r5/10_final/bench_driver_like.json): the same contract with this round's traffic record; the host-pointer
+    # rates on page-locked arrays and at 8 slices per call ride along (never `value`)
+    l5 = json.loads(open(os.path.join(root, "profiles", "r5", "10_final", "bench_driver_like.json")).read().strip().splitlines()[-1])
+    r5 = l5["roofline"]
+    assert r5["kernel"] == "siren_trunk_f16x3n_kernel<0,3,5>" and r5["flops_per_launch"] == 525824 * 576 * 400
+    assert abs(l5["value"] - 320 * 320 / (l5["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * l5["value"]
+    assert abs(r5["frac"] - r5["achieved"] / r5["peak"]) < 1e-9 and "profiles/r5/" in r5["traffic_source"] and 1e7 < r5["traffic"] < 3e7
+    assert l5["roofline_kernel_alone"]["kernel"] == "siren_trunk_f16x3w_kernel<0,4>" and l5["cpu_baseline"]["kind"] == "port"
+    e5 = l5["extra"]
+    assert 0 < e5["host_to_host_mpixel_s"] < e5["host_to_host_pinned_mpixel_s"] < l5["value"] and e5["host_to_host_8_slices_mpixel_s"] > e5["host_to_host_mpixel_s"]
+    for name in ("config3_64_slices_n1", "config3_64_slices_n1_one_stream", "config3_8_slices_per_rank", "config4_morlet", "fp32_trunk",
+                 "config5_deep_residual_bf16"):
+        assert e5["configs"][name]["value"] > 0, name
+    traffic = json.load(open(os.path.join(root, "profiles", "r5", "traffic.json")))
+    assert {k["kernel"] for k in traffic["kernels"]} >= {"siren_trunk_f16x3n_kernel<0,3,5>", "siren_trunk_f16x3w_kernel<0,4>", "latent_mods_f16x3_kernel<2,2,8,3>",
+                                                          "siren_trunk_x1w_kernel<1,0,1>"}
     # the strong-scaling form of BASELINE configs[2] on one GPU, and its 4-rank rehearsal on one card
     for name, n in (("bench_strong64_n1.json", 1), ("bench_strong64_gloo4_one_card.json", 4)):
         s = json.loads(open(os.path.join(root, "profiles", "r2", "10_final", name)).read().strip().splitlines()[-1])
