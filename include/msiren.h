@@ -259,8 +259,9 @@ MSIREN_API int msiren_dev_alloc(msiren_handle h, size_t bytes, void** dev_ptr);
 MSIREN_API int msiren_dev_free(msiren_handle h, void* dev_ptr);
 /* Page-locked host memory (round 5).  A host-pointer entry point that is handed buffers from here -- or any memory the HIP
  * runtime has page-locked: a torch tensor after .pin_memory(), what the reference's DataLoader delivers with pin_memory=True --
- * copies by DMA without the runtime's staging buffers and without blocking the caller (one 320x320 slice, numpy -> numpy:
- * 437 -> 394 us).  Nothing else changes: same results, bit for bit. */
+ * is not copied at all in a call of fewer than 800 tiles: the conv kernel reads the caller's tiles and the trunk stores into the
+ * caller's output array in place (one 320x320 slice, numpy -> numpy: 437 -> 360 us); cut calls copy by DMA without staging.
+ * Nothing else changes: same results, bit for bit. */
 MSIREN_API int msiren_host_alloc(msiren_handle h, size_t bytes, void** host_ptr);
 MSIREN_API int msiren_host_free(msiren_handle h, void* host_ptr);
 MSIREN_API int msiren_memcpy_h2d(msiren_handle h, void* dst_dev, const void* src_host, size_t bytes);

@@ -138,6 +138,7 @@ struct msiren_ctx {
     int cus_limit = 256;       // MSIREN_GRID: cap on the persistent grids
     int ring_force = 0;        // MSIREN_F16_RING: 3 / 4 forces the weight ring depth of the register-resident trunk
     int half_allowed = 1;      // MSIREN_F16_HALF=0: never use the half-unit instance
+    int zc_out = 1, zc_in = 1;  // MSIREN_ZC_OUT / MSIREN_ZC_IN: kernels write / read page-locked caller buffers in place (A/B knobs)
     int host_pipe_min = 800;   // MSIREN_HOST_PIPE_MIN: tiles from which a host call pipelines itself (one slice: one chunk is as fast, profiles/r5)
     int host_first = 112, host_piece = 400;  // MSIREN_HOST_FIRST / MSIREN_HOST_PIECE: tiles in the first / the further chunks of a pipelined host call
     int host_chunks = 0;       // MSIREN_HOST_CHUNKS: chunks a synchronous host call cuts itself into (0 = default)
@@ -1475,6 +1476,17 @@ int forward_tiles_dev(msiren_ctx* h, const float* tiles_dev, int64_t B, float* o
     return launch_trunk(h, mods, B, out_dev);
 }
 
+// Device address of page-locked host memory (msiren_host_alloc, hipHostMalloc / hipHostRegister of any origin, e.g. a pinned torch tensor);
+// nullptr for ordinary pageable memory.  With it a kernel can read / write the caller's buffer itself -- no copy, no staging.
+void* host_pinned_dev(const void* p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // (pageable memory is "invalid value" to the runtime: not an error of ours)
+        return nullptr;
+    }
+    return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
+}
+
 // the f16x3 domain guard's flag in host memory: raised by a conditional exact-fp32 trunk launch that had to run
 bool take_range_flag(msiren_ctx* h) {
     if (!h->status_host || !*h->status_host) return false;
@@ -1672,6 +1684,8 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_GRID")) h->cus_limit = std::max(1, std::min(h->num_cus, std::atoi(e)));
     if (const char* e = std::getenv("MSIREN_F16_RING")) h->ring_force = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_F16_HALF")) h->half_allowed = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_ZC_OUT")) h->zc_out = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_ZC_IN")) h->zc_in = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_HOST_PIPE_MIN")) h->host_pipe_min = std::max(128, std::atoi(e));
     if (const char* e = std::getenv("MSIREN_HOST_FIRST")) h->host_first = std::max(16, std::atoi(e));
     if (const char* e = std::getenv("MSIREN_HOST_PIECE")) h->host_piece = std::max(64, std::atoi(e));
@@ -1964,6 +1978,14 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     }
     const int nchunks = (int)plan.size();
     const size_t tile_elems = (size_t)h->O * h->O;
+    // Page-locked buffers (round 5): the trunk stores its 0.9 MB per slice straight into the caller's output array over the course of its
+    // 265 us -- no download, no wait for one behind the stream -- and the conv kernel reads the caller's tiles in place.
+    // One-chunk calls only: same box, 400 tiles: 390 us with both copies, 369 with the output in place, 360 with the tiles in place as well;
+    // a cut call of 3 200 tiles: 2.24 ms with copies (they run beside the other chunk's kernels anyway), 2.35-2.87 ms in place
+    // (tools/host_zero_copy_ab.py, profiles/r5/04_host_call_pipelining.txt).
+    float* const out_zc = h->zc_out && nchunks == 1 ? (float*)host_pinned_dev(out_host) : nullptr;
+    const float* const in_zc = h->zc_in && nchunks == 1 && out_zc ? (const float*)host_pinned_dev(tiles_host) : nullptr;
+    float* const out_base = out_zc ? out_zc : (float*)h->ws_out.p;
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     auto us = [&]() { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
@@ -1978,7 +2000,9 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     h->no_split = pipelined;
     auto download = [&](int k) {
         const Chunk& c = plan[k];
-        hipError_t e = hipMemcpyAsync(out_host + (size_t)c.lo * h->P, (float*)h->ws_out.p + (size_t)c.lo * h->P, (size_t)c.n * h->P * sizeof(float),
+        tr_d2h[k] = us();
+        if (out_zc) return;
+        hipError_t e = hipMemcpyAsync(out_host + (size_t)c.lo * h->P, out_base + (size_t)c.lo * h->P, (size_t)c.n * h->P * sizeof(float),
                                       hipMemcpyDeviceToHost, h->sc[c.stream].s);
         if (e != hipSuccess && !rc) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(D2H): %s", hipGetErrorString(e));
         tr_d2h[k] = us();
@@ -1988,14 +2012,16 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
         h->cur = c.stream;
         h->trunk_force = c.trunk;
         h->em_beside = c.beside;
-        float* d_t = (float*)h->ws_tiles.p + (size_t)c.lo * tile_elems;
-        hipError_t e = hipMemcpyAsync(d_t, tiles_host + (size_t)c.lo * tile_elems, (size_t)c.n * tile_elems * sizeof(float), hipMemcpyHostToDevice, h->sc[c.stream].s);
-        if (e != hipSuccess) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(H2D): %s", hipGetErrorString(e));
+        const float* d_t = in_zc ? in_zc + (size_t)c.lo * tile_elems : (const float*)h->ws_tiles.p + (size_t)c.lo * tile_elems;
+        if (!in_zc) {
+            hipError_t e = hipMemcpyAsync((void*)d_t, tiles_host + (size_t)c.lo * tile_elems, (size_t)c.n * tile_elems * sizeof(float), hipMemcpyHostToDevice, h->sc[c.stream].s);
+            if (e != hipSuccess) rc = fail(MSIREN_E_HIP, "hipMemcpyAsync(H2D): %s", hipGetErrorString(e));
+        }
         tr_h2d[k] = us();
         // (the weight-stationary trunk owns its CUs: queued beside the previous chunk's conditional exact-fp32 launch it would start first,
         //  and that launch -- and the download behind it -- would wait for it to end)
         if (pipelined && c.trunk == 2 && k >= 1 && !rc) h->trunk_after = h->sc[plan[k - 1].stream].ev_join;
-        if (!rc) rc = forward_tiles_dev(h, d_t, c.n, (float*)h->ws_out.p + (size_t)c.lo * h->P);
+        if (!rc) rc = forward_tiles_dev(h, d_t, c.n, out_base + (size_t)c.lo * h->P);
         if (pipelined && !rc) {
             auto& sc = h->sc[c.stream];
             if (!sc.ev_join) { hipError_t e2 = hipEventCreateWithFlags(&sc.ev_join, hipEventDisableTiming); if (e2 != hipSuccess) rc = fail(MSIREN_E_HIP, "hipEventCreate: %s", hipGetErrorString(e2)); }
