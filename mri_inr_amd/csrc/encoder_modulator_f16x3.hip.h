@@ -36,6 +36,7 @@
 #include <type_traits>
 
 #include "encoder_params.h"  // EncoderParams, leaky02
+#include "host_plan.h"       // em_ring_depth_ok: the rule the packer, the kernel and the CPU test share
 
 namespace msiren {
 
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 5 : (DEPTH == 4 ? 2 : 1)) void la
     constexpr int RMAX = (HIMG + H * 4) * 16;         // byte offset of the 4 x 16 row maxima
     // ring slot of a k-step = its position in the wave's stream modulo DEPTH, and every slot index is a compile-time constant:
     // the stages whose count is a run-time value (L layers) must advance the position by a multiple of DEPTH per iteration
-    static_assert((EM_C3_KSTEPS / 2) % DEPTH == 0 && (NPH * KZ) % DEPTH == 0 && (NPH * KH) % DEPTH == 0, "ring depth must divide every layer");
+    static_assert(em_ring_depth_ok(NPH, NPZ, DEPTH, EM_C3_KSTEPS / 2), "ring depth must divide every layer");
     constexpr int PHZ = (NPZ * EM_FC_KSTEPS) % DEPTH;  // ring phase at which the z stage (and every layer behind it) starts
     constexpr bool EARLY = DEPTH > 2;  // fetch what an epilogue reads from global memory in front of its K loop (costs 8 registers)
     constexpr int BD = DEPTH < 8 ? DEPTH : 8;           // conv3's B images come from HBM / L2 as well: their own, shallower ring

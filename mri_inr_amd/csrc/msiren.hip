@@ -26,6 +26,7 @@
 #include "encoder_modulator_f16x3.hip.h"
 #include "mfma_probe.hip.h"
 #include "pass_queue.h"
+#include "host_plan.h"
 #include "weights_blob.h"
 #include "siren_trunk_f16x3n.hip.h"
 #include "siren_trunk_f16x3h.hip.h"
@@ -612,8 +613,8 @@ int pack_prologue_f16x3(msiren_ctx* h) {
         (void)std::frexp(mx, &e);  // mx = f 2^e, f in [0.5, 1)
         return std::max(-100, std::min(100, 14 - e));
     };
-    const int zp_start = enc ? msiren::EM_C3_KSTEPS / 2 + NPZ * msiren::EM_FC_KSTEPS : 0;
-    const int nk = zp_start + (mod ? L * NPH * KZ + (L - 1) * NPH * KH : 0);
+    const msiren::EmStreamLayout lay = msiren::em_stream_layout(NPH, NPZ, L, enc, mod, msiren::EM_C3_KSTEPS / 2, msiren::EM_FC_KSTEPS);  // (host_plan.h)
+    const int zp_start = lay.zp_start, nk = lay.total;
     std::vector<uint16_t> ws(((size_t)4 * nk + msiren::EM_MAX_DEPTH) * 4 * 64 * 8, 0);  // (+ padding: the ring prefetches past the end)
     auto put = [&](int wave, int g, int t, int lane, int j, double v) {  // v already scaled
         const float f = (float)v;
@@ -1950,23 +1951,12 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     // trunk (the faster kernel; nothing is left to run beside it but the previous chunk's download).  All trunk and prologue
     // instances give the same bits, so the cut does not change results (tests/test_gpu_split.py).
     // MSIREN_HOST_CHUNKS=1: one chunk on one stream (rounds 3-4); =2 with MSIREN_HOST_SPLIT: the even two-chunk cut of round 2.
-    struct Chunk { int64_t lo, n; int stream, trunk; bool beside; };
+    using Chunk = msiren::HostChunk;
     std::vector<Chunk> plan;
     const int cur0 = h->cur;
-    // (page-locked buffers -- msiren_host_alloc, a pinned torch tensor -- need nothing special here: hipMemcpyAsync then is DMA without staging and
-    //  does not block: one slice 437 -> 394 us in one chunk; cutting it pays from two slices up as with pageable memory, 406 us at one --
-    //  profiles/r5/04_host_call_pipelining.txt)
     const bool pipelined = h->host_chunks == 0 && B >= h->host_pipe_min && use_f16x3(h) && !h->x1_ready && h->L == 5 && h->em_enc && h->em_mod && ws_capable(h, B);
     if (pipelined) {
-        const int64_t first = std::min<int64_t>(h->host_first, std::max<int64_t>(16, B / 3)), piece = h->host_piece;
-        plan.push_back({0, first, cur0, 1, false});
-        for (int64_t lo = first; lo < B;) {
-            int64_t n = std::min<int64_t>(piece, B - lo);
-            if (B - lo - n < 128) n = B - lo;  // (no tiny last chunk)
-            const bool last = lo + n == B;
-            plan.push_back({lo, n, (int)(plan.size() & 1) ^ cur0, last ? 2 : 1, true});
-            lo += n;
-        }
+        plan = msiren::pipelined_host_plan(B, h->host_first, h->host_piece, cur0);  // (host_plan.h: unit-tested on the CPU)
     } else {
         int nchunks = std::max(1, h->host_chunks);
         nchunks = (int)std::min<int64_t>(nchunks, B);
