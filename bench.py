@@ -727,7 +727,7 @@ def other_configs(launch_timeout=90.0, wall_budget=240.0):
         "config3_64_slices_n1": (["--total-slices", "64", "--steps", "24", "--warmup", "3"],
                                  "BASELINE configs[2]: 64 slices = 25600 tiles per call, one GPU, two streams"),
         "config3_64_slices_n1_one_stream": (["--total-slices", "64", "--streams", "1", "--steps", "24", "--warmup", "3"],
-                                            "the same on a one-stream handle: the call is cut in two and overlaps with itself"),
+                                            "the same on a one-stream handle: one weight-stationary trunk launch behind the call's whole prologue"),
         "config3_8_slices_per_rank": (["--slices", "8", "--steps", "120", "--warmup", "10"],
                                       "8 slices = 3200 tiles per call: one rank's share of configs[2] on 8 GPUs"),
         "config4_morlet": (["--activation", "morlet", "--steps", "600", "--warmup", "30"], "BASELINE configs[3]: Morlet activation, one slice per call"),

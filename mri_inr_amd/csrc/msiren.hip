@@ -89,7 +89,11 @@ struct msiren_ctx {
                                        // trunk of the last chunk behind the other stream's conditional launch, which cannot run beside it)
     bool no_split = false;   // a host call that pipelines itself: its chunks are not cut again by forward_tiles_split
     bool em_beside = false;  // the prologue being launched runs beside a trunk of this call (forward_tiles_split): shallow weight ring
-    int64_t split_min = 3200;  // MSIREN_SPLIT_MIN: *_dev forward calls of at least this many tiles are cut in two (0 = never)
+    // MSIREN_SPLIT_MIN: *_dev forward calls of at least this many tiles on a one-stream handle are cut in two (forward_tiles_split; 0 = never).
+    // Round 4 shipped 3200: the prologue was eight latency-bound launches, 1.3 of 17.2 ms at 64 slices, worth hiding behind the call's own first
+    // trunk.  With round 5's one-launch prologue (0.5 ms of L2-bound streaming that slows the trunk it runs beside by what it saves) every cut is
+    // within 0.5 % of the uncut call at 64 slices and 2-4 % behind it at 8 (profiles/r5/07_*): off by default; the mechanism and its tests stay.
+    int64_t split_min = 0;
     int split_pct = 12;        // MSIREN_SPLIT_PCT: share of the first part, percent
     int lin_tile_min = 1024;   // MSIREN_LINEAR_TILE_MIN: rows from which the Linear layers use the 32 x 32-tile kernel (0 = never)
     bool lin_tile_env = false; // (set by the knob: then it holds for every layer width)
@@ -1413,7 +1417,7 @@ int forward_latent_dev(msiren_ctx* h, const float* z_dev, int64_t B, float* out_
     return launch_trunk(h, mods, B, out_dev);
 }
 
-// ---- large calls: hide the encoder + modulator of most of the batch behind the trunk of its first part ----------------
+// ---- large calls: hide the encoder + modulator of most of the batch behind the trunk of its first part (opt-in since round 5) ----------------
 // One big call cannot overlap with itself: its prologue (conv1/conv2, conv3, Linear, L Modulator layers -- 20 us per
 // 400 tiles at throughput sizes) ran in front of a trunk that then had the chip to itself: 1.3 of 17.2 ms for 64 slices.
 // The weight-stationary trunk leaves no room beside it, the register-resident one does.  So a call of

@@ -1,7 +1,8 @@
 """Large asynchronous calls overlap with themselves (mri_inr_amd/csrc/msiren.hip: forward_tiles_split), and the paths the
 benchmark's timed region runs are checked against the reference's fixtures DIRECTLY (not through another path's output).
 
-On a one-stream handle a call of >= 3200 tiles is cut in two: the encoder + Modulator of most of the batch run on the handle's other stream
+With MSIREN_SPLIT_MIN=3200 (round 4's default; off since round 5: with the one-launch prologue the uncut call is as fast or faster,
+profiles/r5/07_*) a call of >= 3200 tiles on a one-stream handle is cut in two: the encoder + Modulator of most of the batch run on the handle's other stream
 beside the register-resident trunk of the first part, the weight-stationary trunk of the rest follows.  Patches are
 independent (modulated_siren.py:435-457) and the two trunks give the same bits, so nothing may change.
 """
@@ -50,7 +51,7 @@ def test_split_call_same_bits_as_uncut_call(act):
     check(ref[:32], orc.modulated_siren_forward(sd, tiles[:32], num_layers=5, activation=act, dtype=np.float64))
     check(ref[-32:], orc.modulated_siren_forward(sd, tiles[-32:], num_layers=5, activation=act, dtype=np.float64))
     a = 1 if act == "morlet" else 0
-    for env in ({}, {"MSIREN_SPLIT_PCT": 30}, {"MSIREN_SPLIT_PCT": 1}, {"MSIREN_SPLIT_MIN": 3300}):
+    for env in ({"MSIREN_SPLIT_MIN": 3200}, {"MSIREN_SPLIT_MIN": 3200, "MSIREN_SPLIT_PCT": 30}, {"MSIREN_SPLIT_MIN": 3200, "MSIREN_SPLIT_PCT": 1}, {"MSIREN_SPLIT_MIN": 3300}):
         m = make_with_env(sd, env, act=act, precision="f16x3")
         d_i, d_o = m.device_array(tiles.shape).copy_from(tiles), [m.device_array((B, 24, 24)) for _ in range(2)]
         for streams in (1, 2):
@@ -80,17 +81,17 @@ def test_split_call_same_bits_as_uncut_call(act):
 
 
 def test_split_is_not_taken_where_it_does_not_apply():
-    """Other depths, the exact-fp32 trunk and the masked slice pipeline (tile count known to the device only) run uncut."""
+    """(with MSIREN_SPLIT_MIN=3200) Other depths, the exact-fp32 trunk and the masked slice pipeline (tile count known to the device only) run uncut."""
     tiles = np.random.default_rng(12).random((3300, 32, 32), dtype=np.float32)
     for L, prec in ((4, "f16x3"), (5, "fp32")):
         sd = syn.make_state_dict(seed=3, num_layers=L, trained_like=True)
-        m = make_model(sd, L=L, precision=prec)
+        m = make_with_env(sd, {"MSIREN_SPLIT_MIN": 3200}, L=L, precision=prec)
         _lib.check(m._lib.msiren_profile_enable(m._h, 1))
         out = m(tiles)
         assert len(m.profile_kernels()) == 1
         check(out[:16], orc.modulated_siren_forward(sd, tiles[:16], num_layers=L, dtype=np.float64))
     sd = syn.make_state_dict(seed=7, trained_like=True)
-    m = make_model(sd)
+    m = make_with_env(sd, {"MSIREN_SPLIT_MIN": 3200})
     imgs = np.stack([syn.make_slice(k, brain_mask=True) for k in range(9)])
     _lib.check(m._lib.msiren_profile_enable(m._h, 1))
     rec = m.reconstruct(imgs)
@@ -204,13 +205,13 @@ def test_host_call_of_several_slices_pipelines_itself_same_bits():
 
 
 def test_out_of_domain_modulation_in_the_second_part_of_a_cut_call():
-    """A >= 3200-tile call on a one-stream handle is cut in two (forward_tiles_split); a tile whose modulations leave the fp16
+    """With MSIREN_SPLIT_MIN=3200 a >= 3200-tile call on a one-stream handle is cut in two (forward_tiles_split); a tile whose modulations leave the fp16
     domain lies in the SECOND part: that part's launch is repaired by the conditional exact-fp32 trunk (which reads mods2 with
     p.B = B1), the first part keeps its split-fp16 bits."""
     sd = syn.make_state_dict(seed=7, trained_like=True)
     B = 3300
     tiles = np.random.default_rng(23).random((B, 32, 32), dtype=np.float32)
-    m = make_model(sd, precision="f16x3")
+    m = make_with_env(sd, {"MSIREN_SPLIT_MIN": 3200}, precision="f16x3")
     clean = m(tiles)
     bad = tiles.copy()
     bad[3000] *= 3e7          # latent ~1e7 -> modulations far beyond 65504
@@ -267,3 +268,19 @@ def test_page_locked_buffers_same_bits_recycled_and_outlive_the_model():
     import gc
     gc.collect()
     assert np.array_equal(again, ref) and np.array_equal(keep, ref) and np.array_equal(pin, tiles)
+
+
+def test_by_default_a_large_call_on_a_one_stream_handle_is_one_trunk_launch():
+    """Round 5: MSIREN_SPLIT_MIN defaults to 0 -- behind the one-launch prologue the uncut call is as fast at 64 slices and faster at 8
+    (profiles/r5/07_*)."""
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = make_model(sd, precision="f16x3")
+    tiles = np.random.default_rng(3).random((3300, 32, 32), dtype=np.float32)
+    d_in, d_out = m.device_array(tiles.shape).copy_from(tiles), m.device_array((3300, 24, 24))
+    _lib.check(m._lib.msiren_profile_enable(m._h, 1))
+    run_dev(m, d_in, 3300, d_out)
+    m.sync()
+    ks = m.profile_kernels()
+    assert len(ks) == 1 and ks[0]["kernel"] == "siren_trunk_f16x3w_kernel<0,4>" and ks[0]["coords"] == 3300 * 576, ks
+    cut = make_with_env(sd, {"MSIREN_SPLIT_MIN": 3200}, precision="f16x3")
+    assert np.array_equal(d_out.numpy(), cut(tiles))
