@@ -143,6 +143,7 @@ struct msiren_ctx {
     int cus_limit = 256;       // MSIREN_GRID: cap on the persistent grids
     int ring_force = 0;        // MSIREN_F16_RING: 3 / 4 forces the weight ring depth of the register-resident trunk
     int half_allowed = 1;      // MSIREN_F16_HALF=0: never use the half-unit instance
+    int host_register = 1;     // MSIREN_HOST_REGISTER=0: pageable caller buffers are never page-locked for the duration of a call (A/B knob)
     int zc_out = 1, zc_in = 1;  // MSIREN_ZC_OUT / MSIREN_ZC_IN: kernels write / read page-locked caller buffers in place (A/B knobs)
     int host_pipe_min = 800;   // MSIREN_HOST_PIPE_MIN: tiles from which a host call pipelines itself (one slice: one chunk is as fast, profiles/r5)
     int host_first = 112, host_piece = 400;  // MSIREN_HOST_FIRST / MSIREN_HOST_PIECE: tiles in the first / the further chunks of a pipelined host call
@@ -1492,6 +1493,60 @@ void* host_pinned_dev(const void* p) {
     return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
 }
 
+// Device view of a caller's host buffer for the duration of one call: page-locked memory of the caller's own as it is; ordinary pageable memory
+// through hipHostRegister, released again by the destructor.  Registrations are PROCESS-WIDE and reference-counted: two handles in two threads
+// that are handed the same array (or a slice of it) share one registration, and the first call to return does not unlock the pages under the
+// other's kernels.  A range that only partly overlaps a registered one is refused by the runtime: that call copies (its pageable copies are staged,
+// whatever happens to the neighbour's registration).
+class HostLock {
+    struct Entry { size_t bytes; void* dev; int refs; };
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::map<uintptr_t, Entry>& table() { static std::map<uintptr_t, Entry> t; return t; }
+    uintptr_t base_ = 0;  // key of the registration this object holds a reference to (0: none)
+
+public:
+    HostLock() = default;
+    HostLock(const HostLock&) = delete;
+    HostLock& operator=(const HostLock&) = delete;
+    ~HostLock() {
+        if (!base_) return;
+        std::lock_guard<std::mutex> g(mu());
+        auto it = table().find(base_);
+        if (it != table().end() && --it->second.refs == 0) {
+            (void)hipHostUnregister((void*)base_);
+            table().erase(it);
+        }
+    }
+    void* device_view(const void* host, size_t bytes, bool may_register) {
+        const uintptr_t a = (uintptr_t)host;
+        std::lock_guard<std::mutex> g(mu());  // (one critical section: of two threads that come with the same new buffer, the second finds the first's entry)
+        auto it = table().upper_bound(a);     // a registration of ours that contains the range: share it
+        if (it != table().begin()) {
+            --it;
+            if (a >= it->first && a + bytes <= it->first + it->second.bytes) {
+                it->second.refs++;
+                base_ = it->first;
+                return (char*)it->second.dev + (a - it->first);
+            }
+        }
+        if (void* d = host_pinned_dev(host)) return d;  // the caller's own page-locked memory
+        if (!may_register) return nullptr;
+        if (hipHostRegister((void*)host, bytes, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, (void*)host, 0) != hipSuccess || !d) {
+            (void)hipGetLastError();
+            (void)hipHostUnregister((void*)host);
+            return nullptr;
+        }
+        table()[a] = Entry{bytes, d, 1};
+        base_ = a;
+        return d;
+    }
+};
+
 // the f16x3 domain guard's flag in host memory: raised by a conditional exact-fp32 trunk launch that had to run
 bool take_range_flag(msiren_ctx* h) {
     if (!h->status_host || !*h->status_host) return false;
@@ -1689,6 +1744,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_GRID")) h->cus_limit = std::max(1, std::min(h->num_cus, std::atoi(e)));
     if (const char* e = std::getenv("MSIREN_F16_RING")) h->ring_force = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_F16_HALF")) h->half_allowed = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_HOST_REGISTER")) h->host_register = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_ZC_OUT")) h->zc_out = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_ZC_IN")) h->zc_in = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_HOST_PIPE_MIN")) h->host_pipe_min = std::max(128, std::atoi(e));
@@ -1977,8 +2033,15 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     // One-chunk calls only: same box, 400 tiles: 390 us with both copies, 369 with the output in place, 360 with the tiles in place as well;
     // a cut call of 3 200 tiles: 2.24 ms with copies (they run beside the other chunk's kernels anyway), 2.35-2.87 ms in place
     // (tools/host_zero_copy_ab.py, profiles/r5/04_host_call_pipelining.txt).
-    float* const out_zc = h->zc_out && nchunks == 1 ? (float*)host_pinned_dev(out_host) : nullptr;
-    const float* const in_zc = h->zc_in && nchunks == 1 && out_zc ? (const float*)host_pinned_dev(tiles_host) : nullptr;
+    // Pageable buffers of a one-chunk call of >= 64 tiles are page-locked for the duration of the call (hipHostRegister: 4-6 us for a slice's
+    // 1.6 + 0.9 MB on this system, tools/host_register_cost.py) and then treated alike: numpy -> numpy 419 -> 358 us.  If the runtime refuses
+    // (a range that overlaps a registered one, no memory to lock) the call copies as before.  (HostLock: process-wide, reference-counted.)
+    HostLock reg_out, reg_in;  // (released when the call returns: behind sync_all)
+    const bool may_lock = h->host_register && B >= 64;
+    float* out_zc_ = h->zc_out && nchunks == 1 ? (float*)reg_out.device_view(out_host, no, may_lock) : nullptr;
+    const float* in_zc_ = h->zc_in && nchunks == 1 && out_zc_ ? (const float*)reg_in.device_view(tiles_host, nt, may_lock) : nullptr;
+    float* const out_zc = out_zc_;
+    const float* const in_zc = in_zc_;
     float* const out_base = out_zc ? out_zc : (float*)h->ws_out.p;
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();

@@ -819,6 +819,42 @@ def test_two_handles_from_two_threads():
     assert not errors, errors[:5]
 
 
+def test_two_threads_share_one_pageable_input_array():
+    """Round 5: a one-chunk host call page-locks its pageable buffers for its duration and lets the kernels read / write them in place.  Two
+    handles in two threads that are handed THE SAME input array (and slices of it) share one reference-counted registration: the call that
+    returns first must not unlock the pages under the other's kernels.  Every output equals the single-threaded one; nothing faults."""
+    import threading
+
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    shared = np.random.default_rng(77).random((400, 32, 32), dtype=np.float32)
+    models = [make_model(sd, precision="f16x3") for _ in range(2)]
+    ref = models[0](shared)
+    assert np.array_equal(models[1](shared), ref)
+    errors = []
+
+    def work(i):
+        try:
+            for k in range(40):
+                lo = (37 * (k + i)) % 200 if k % 3 else 0          # the whole array, and slices of it that lie inside the other thread's range
+                x = shared[lo:] if k % 3 else shared
+                out = models[i](x)
+                if not np.array_equal(out, ref[lo:]):
+                    errors.append((i, k, float(np.abs(out - ref[lo:]).max())))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors[:5]
+    # without the per-call page-locking (MSIREN_HOST_REGISTER=0: staged copies) the same bits
+    from test_gpu_split import make_with_env
+    plain = make_with_env(sd, {"MSIREN_HOST_REGISTER": 0}, precision="f16x3")
+    assert np.array_equal(plain(shared), ref)
+
+
 @pytest.mark.parametrize("start", ["0xFFFFF800", "0x7FFFF800"])
 def test_pass_counter_wraps_safely(start):
     """The persistent trunks' pass counter is never reset (the host tells each launch the value it will find), so
