@@ -257,11 +257,13 @@ MSIREN_API int msiren_comm_destroy(msiren_handle h);
 
 MSIREN_API int msiren_dev_alloc(msiren_handle h, size_t bytes, void** dev_ptr);
 MSIREN_API int msiren_dev_free(msiren_handle h, void* dev_ptr);
-/* Page-locked host memory (round 5).  A host-pointer entry point that is handed buffers from here -- or any memory the HIP
- * runtime has page-locked: a torch tensor after .pin_memory(), what the reference's DataLoader delivers with pin_memory=True --
- * is not copied at all in a call of fewer than 800 tiles: the conv kernel reads the caller's tiles and the trunk stores into the
- * caller's output array in place (one 320x320 slice, numpy -> numpy: 437 -> 360 us); cut calls copy by DMA without staging.
- * Nothing else changes: same results, bit for bit. */
+/* Host buffers of the host-pointer entry points (round 5).  msiren_forward_tiles of fewer than 2400 tiles runs as ONE chunk whose kernels
+ * read the caller's tiles and store into the caller's output array IN PLACE: page-locked memory -- from here, or any memory the HIP runtime
+ * has page-locked: a torch tensor after .pin_memory(), what the reference's DataLoader delivers with pin_memory=True -- as it is; ordinary
+ * pageable memory (a numpy array) is page-locked by the library for the duration of the call (hipHostRegister, a few microseconds;
+ * process-wide and reference-counted, so threads may share an input array) -- one 320x320 slice numpy -> numpy: 437 -> 359 us.  Larger
+ * calls cut themselves into chunks over the handle's two streams, with copies that run beside the other chunk's kernels.
+ * Same results either way, bit for bit. */
 MSIREN_API int msiren_host_alloc(msiren_handle h, size_t bytes, void** host_ptr);
 MSIREN_API int msiren_host_free(msiren_handle h, void* host_ptr);
 MSIREN_API int msiren_memcpy_h2d(msiren_handle h, void* dst_dev, const void* src_host, size_t bytes);

@@ -145,7 +145,7 @@ struct msiren_ctx {
     int half_allowed = 1;      // MSIREN_F16_HALF=0: never use the half-unit instance
     int host_register = 1;     // MSIREN_HOST_REGISTER=0: pageable caller buffers are never page-locked for the duration of a call (A/B knob)
     int zc_out = 1, zc_in = 1;  // MSIREN_ZC_OUT / MSIREN_ZC_IN: kernels write / read page-locked caller buffers in place (A/B knobs)
-    int host_pipe_min = 800;   // MSIREN_HOST_PIPE_MIN: tiles from which a host call pipelines itself (one slice: one chunk is as fast, profiles/r5)
+    int host_pipe_min = 2400;  // MSIREN_HOST_PIPE_MIN: tiles from which a host call cuts itself into chunks (below: one chunk, buffers in place; profiles/r5/04_*)
     int host_first = 112, host_piece = 400;  // MSIREN_HOST_FIRST / MSIREN_HOST_PIECE: tiles in the first / the further chunks of a pipelined host call
     int host_chunks = 0;       // MSIREN_HOST_CHUNKS: chunks a synchronous host call cuts itself into (0 = default)
     unsigned queue_start = 0;  // MSIREN_QUEUE_START: initial value of the never-reset pass counters
@@ -2003,10 +2003,10 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     //     H2D_0 | launch_0 | H2D_1 | launch_1 | D2H_0 | H2D_2 | launch_2 | D2H_1 | ... | D2H_last
     // (a pageable copy blocks the host until it is done -- so each is issued where the device has other work queued).
     // Chunk 0 is SMALL (112 tiles = two rounds of the register-resident trunk): its upload is short, so the device starts early,
-    // and its trunk runs while the next chunk's tiles arrive and its encoder / Modulator run beside it.  From 800 tiles (two slices)
-    // up: 8 slices per call 2.57 -> 2.27 ms (318 -> 361 Mpixel/s); a single slice is as fast in one chunk (428 us either way: the
-    // second chunk's encoder + Modulator, 73 us beside the first chunk's trunk, end up on the critical path) --
-    // profiles/r5/04_host_call_pipelining.txt.  Every chunk but the
+    // and its trunk runs while the next chunk's tiles arrive and its encoder / Modulator run beside it.  From 2400 tiles (six slices)
+    // up: 8 slices per call 2.57 -> 2.27 ms with staged copies; below, ONE chunk whose kernels read / write the caller's buffers in
+    // place (page-locked for the call's duration) is faster: 800 tiles 658 against 818 us, 1600 tiles 1220 against 1227, 3200 tiles
+    // 2353 against 2284 -- profiles/r5/04_host_call_pipelining.txt.  Every chunk but the
     // last takes the register-resident trunk (room beside it for the next chunk's prologue), the last one the weight-stationary
     // trunk (the faster kernel; nothing is left to run beside it but the previous chunk's download).  All trunk and prologue
     // instances give the same bits, so the cut does not change results (tests/test_gpu_split.py).

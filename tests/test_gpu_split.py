@@ -174,7 +174,7 @@ def test_tiled_linear_layers_same_bits_as_the_16x16_kernel(H, Z, L, B):
 
 
 def test_host_call_of_several_slices_pipelines_itself_same_bits():
-    """A numpy -> numpy call of >= 800 tiles cuts itself into chunks over the handle's two streams (uploads and downloads beside the
+    """A numpy -> numpy call of >= MSIREN_HOST_PIPE_MIN tiles (default 2400; 800 / 128 here) cuts itself into chunks over the handle's two streams (uploads and downloads beside the
     other chunk's kernels; msiren_forward_tiles_impl).  Patches are independent and every trunk / prologue instance gives the same
     bits, so nothing may change -- also with asynchronous *_dev work still pending on the helper stream of a two-stream handle."""
     sd = syn.make_state_dict(seed=7, trained_like=True)
@@ -183,14 +183,14 @@ def test_host_call_of_several_slices_pipelines_itself_same_bits():
     one = make_with_env(sd, {"MSIREN_HOST_CHUNKS": 1, "MSIREN_SPLIT_MIN": 0}, precision="f16x3")
     ref = one(tiles)
     check(ref[:24], orc.modulated_siren_forward(sd, tiles[:24], num_layers=5, dtype=np.float64))
-    for env in ({}, {"MSIREN_HOST_FIRST": 56, "MSIREN_HOST_PIECE": 200}, {"MSIREN_HOST_PIPE_MIN": 128, "MSIREN_HOST_FIRST": 40}):
+    for env in ({"MSIREN_HOST_PIPE_MIN": 800}, {"MSIREN_HOST_PIPE_MIN": 800, "MSIREN_HOST_FIRST": 56, "MSIREN_HOST_PIECE": 200}, {"MSIREN_HOST_PIPE_MIN": 128, "MSIREN_HOST_FIRST": 40}):
         m = make_with_env(sd, env, precision="f16x3")
         _lib.check(m._lib.msiren_profile_enable(m._h, 1))
         assert np.array_equal(m(tiles), ref), env
         ks = {k["kernel"]: k for k in m.profile_kernels()}
         assert set(ks) == {"siren_trunk_f16x3n_kernel<0,3,5>", "siren_trunk_f16x3w_kernel<0,4>"} and sum(k["coords"] for k in ks.values()) == B * 576, ks
         assert ks["siren_trunk_f16x3w_kernel<0,4>"]["launches"] == 1      # the last chunk
-        assert np.array_equal(m(tiles[:500]), ref[:500])                    # (below the threshold with the default knobs: one chunk)
+        assert np.array_equal(m(tiles[:100]), ref[:100])                    # (below the threshold: one chunk, buffers in place)
         # two-stream handle, un-synced device calls on both streams, then the host call
         _lib.check(m._lib.msiren_set_streams(m._h, 2))
         d_in = m.device_array((400, 32, 32)).copy_from(tiles[:400])
@@ -237,7 +237,7 @@ def test_page_locked_buffers_same_bits_recycled_and_outlive_the_model():
     several slices; the pool recycles blocks; arrays stay valid after their model is gone."""
     sd = syn.make_state_dict(seed=7, trained_like=True)
     tiles = np.random.default_rng(31).random((400, 32, 32), dtype=np.float32)
-    m = make_model(sd, precision="f16x3")
+    m = make_with_env(sd, {"MSIREN_HOST_PIPE_MIN": 800}, precision="f16x3")
     ref = m(tiles)                                   # pageable in, pageable out: one chunk
     _lib.check(m._lib.msiren_profile_enable(m._h, 1))
     m(tiles)
@@ -251,7 +251,7 @@ def test_page_locked_buffers_same_bits_recycled_and_outlive_the_model():
     big[...] = np.concatenate([tiles, tiles, tiles[:200]])
     _lib.check(m._lib.msiren_profile_enable(m._h, 1))
     got = m(big)
-    assert len(m.profile_kernels()) == 2                                     # >= 800 tiles: the call cuts itself
+    assert len(m.profile_kernels()) == 2                                     # >= MSIREN_HOST_PIPE_MIN tiles: the call cuts itself
     _lib.check(m._lib.msiren_profile_enable(m._h, 0))
     assert np.array_equal(got[:400], ref) and np.array_equal(got[400:800], ref) and np.array_equal(got[800:], ref[:200])
     del got, big
