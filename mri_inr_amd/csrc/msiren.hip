@@ -1493,59 +1493,149 @@ void* host_pinned_dev(const void* p) {
     return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
 }
 
-// Device view of a caller's host buffer for the duration of one call: page-locked memory of the caller's own as it is; ordinary pageable memory
-// through hipHostRegister, released again by the destructor.  Registrations are PROCESS-WIDE and reference-counted: two handles in two threads
-// that are handed the same array (or a slice of it) share one registration, and the first call to return does not unlock the pages under the
-// other's kernels.  A range that only partly overlaps a registered one is refused by the runtime: that call copies (its pageable copies are staged,
-// whatever happens to the neighbour's registration).
+// A caller's host buffer for the duration of one call.  Three ways through a call, chosen here under ONE process-wide lock:
+//   * device view: page-locked memory of the caller's own as it is; ordinary pageable memory through hipHostRegister (4-6 us for a slice's
+//     buffers), released again by the destructor.  Registrations are reference-counted: two handles in two threads that are handed the same
+//     array (or a window inside it) share one, and the first call to return does not unlock the pages under the other's kernels;
+//   * runtime copies (hipMemcpyAsync on the caller's pointer): the range is entered in a list of ranges being copied, and NO registration is
+//     made over such a range while it is there -- the runtime treats a pointer inside a registration as page-locked (the registration would
+//     end under the copy) and refuses a copy whose range leaves the registration ("invalid argument": tools/soak.py found it);
+//   * bounce buffer (partial()): the range is page-locked in PART -- a neighbour's call on an overlapping window, a caller's own partial
+//     hipHostRegister -- so neither of the above is safe on it: the call copies it by CPU into / out of page-locked memory of its own.
 class HostLock {
     struct Entry { size_t bytes; void* dev; int refs; };
     static std::mutex& mu() { static std::mutex m; return m; }
     static std::map<uintptr_t, Entry>& table() { static std::map<uintptr_t, Entry> t; return t; }
+    static std::vector<std::pair<uintptr_t, size_t>>& copies() { static std::vector<std::pair<uintptr_t, size_t>> c; return c; }
     uintptr_t base_ = 0;  // key of the registration this object holds a reference to (0: none)
+    uintptr_t copy_a_ = 0;
+    size_t copy_n_ = 0;   // the range this object has entered in copies() (0: none)
+    bool partial_ = false;
 
 public:
+    bool partial() const { return partial_; }
     HostLock() = default;
     HostLock(const HostLock&) = delete;
     HostLock& operator=(const HostLock&) = delete;
     ~HostLock() {
-        if (!base_) return;
+        if (!base_ && !copy_n_) return;
         std::lock_guard<std::mutex> g(mu());
-        auto it = table().find(base_);
-        if (it != table().end() && --it->second.refs == 0) {
-            (void)hipHostUnregister((void*)base_);
-            table().erase(it);
+        if (base_) {
+            auto it = table().find(base_);
+            if (it != table().end() && --it->second.refs == 0) {
+                (void)hipHostUnregister((void*)base_);
+                table().erase(it);
+            }
+        }
+        if (copy_n_) {
+            auto& c = copies();
+            for (size_t i = 0; i < c.size(); ++i)
+                if (c[i].first == copy_a_ && c[i].second == copy_n_) {
+                    c[i] = c.back();
+                    c.pop_back();
+                    break;
+                }
         }
     }
+    // device address of the range, or nullptr: then partial() says whether the caller may copy from / to it through the runtime or must bounce
     void* device_view(const void* host, size_t bytes, bool may_register) {
         const uintptr_t a = (uintptr_t)host;
         std::lock_guard<std::mutex> g(mu());  // (one critical section: of two threads that come with the same new buffer, the second finds the first's entry)
-        auto it = table().upper_bound(a);     // a registration of ours that contains the range: share it
+        auto it = table().upper_bound(a);
+        if (it != table().end() && it->first < a + bytes) { partial_ = true; return nullptr; }  // a registration of ours begins inside the range
         if (it != table().begin()) {
             --it;
-            if (a >= it->first && a + bytes <= it->first + it->second.bytes) {
+            if (a >= it->first && a + bytes <= it->first + it->second.bytes) {  // one that contains the range: share it
                 it->second.refs++;
                 base_ = it->first;
                 return (char*)it->second.dev + (a - it->first);
             }
+            if (it->first + it->second.bytes > a) { partial_ = true; return nullptr; }  // one that covers its front
         }
-        if (void* d = host_pinned_dev(host)) return d;  // the caller's own page-locked memory
-        if (!may_register) return nullptr;
-        if (hipHostRegister((void*)host, bytes, hipHostRegisterDefault) != hipSuccess) {
-            (void)hipGetLastError();
+        void* const d_last = bytes > 1 ? host_pinned_dev((const char*)host + bytes - 1) : nullptr;
+        if (void* d = host_pinned_dev(host)) {  // the caller's own page-locked memory -- all of the range, not just its first byte
+            if (bytes <= 1 || d_last == (char*)d + bytes - 1) return d;
+            partial_ = true;
             return nullptr;
         }
-        void* d = nullptr;
-        if (hipHostGetDevicePointer(&d, (void*)host, 0) != hipSuccess || !d) {
-            (void)hipGetLastError();
-            (void)hipHostUnregister((void*)host);
-            return nullptr;
+        if (d_last) { partial_ = true; return nullptr; }
+        bool being_copied = false;
+        for (const auto& c : copies()) being_copied = being_copied || (c.first < a + bytes && a < c.first + c.second);
+        if (may_register && !being_copied) {
+            if (hipHostRegister((void*)host, bytes, hipHostRegisterDefault) == hipSuccess) {
+                void* d = nullptr;
+                if (hipHostGetDevicePointer(&d, (void*)host, 0) == hipSuccess && d) {
+                    table()[a] = Entry{bytes, d, 1};
+                    base_ = a;
+                    return d;
+                }
+                (void)hipGetLastError();
+                (void)hipHostUnregister((void*)host);
+            } else {
+                (void)hipGetLastError();
+            }
         }
-        table()[a] = Entry{bytes, d, 1};
-        base_ = a;
-        return d;
+        copies().emplace_back(a, bytes);
+        copy_a_ = a;
+        copy_n_ = bytes;
+        return nullptr;
     }
 };
+
+// Page-locked memory of one call's own (the bounce buffer of a range that is page-locked in part)
+struct HostBounce {
+    void* p = nullptr;
+    HostBounce() = default;
+    HostBounce(const HostBounce&) = delete;
+    HostBounce& operator=(const HostBounce&) = delete;
+    ~HostBounce() { if (p) (void)hipHostFree(p); }
+    void* alloc(size_t n) {
+        if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+        }
+        return p;
+    }
+};
+
+// A caller's buffer that a synchronous call copies from / to through the runtime: entered in HostLock's list for the call's duration (no
+// registration is made over it meanwhile), a neighbour's registration around it kept alive, a range that is page-locked in part bounced.
+class HostSrc {
+    HostLock lock_;
+    HostBounce b_;
+    const void* p_;
+    bool ok_ = true;
+
+public:
+    HostSrc(const void* host, size_t n) : p_(host) {
+        if (!host || !n) return;
+        (void)lock_.device_view(host, n, false);
+        if (!lock_.partial()) return;
+        if (b_.alloc(n)) { std::memcpy(b_.p, host, n); p_ = b_.p; } else ok_ = false;
+    }
+    bool ok() const { return ok_; }
+    template <typename T> const T* as() const { return (const T*)p_; }
+};
+class HostDst {
+    HostLock lock_;
+    HostBounce b_;
+    void* user_;
+    void* p_;
+    size_t n_;
+    bool ok_ = true;
+
+public:
+    HostDst(void* host, size_t n) : user_(host), p_(host), n_(n) {
+        if (!host || !n) return;
+        (void)lock_.device_view(host, n, false);
+        if (!lock_.partial()) return;
+        if (b_.alloc(n)) p_ = b_.p; else ok_ = false;
+    }
+    bool ok() const { return ok_; }
+    template <typename T> T* as() const { return (T*)p_; }
+    void finish() const { if (b_.p) std::memcpy(user_, b_.p, n_); }  // (behind the stream's synchronisation)
+};
+#define HOSTBUF_OK(x) do { if (!(x).ok()) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer"); } while (0)
 
 // the f16x3 domain guard's flag in host memory: raised by a conditional exact-fp32 trunk launch that had to run
 bool take_range_flag(msiren_ctx* h) {
@@ -1889,10 +1979,15 @@ static int msiren_forward_mods_impl(msiren_handle h, const float* mods_host, int
     if (B == 0) return 0;
     const size_t nm = (size_t)h->L * B * h->H * sizeof(float), no = (size_t)B * h->P * sizeof(float);
     if ((rc = ensure(h, h->sc[h->cur].mods, nm)) || (rc = ensure(h, h->ws_out, no))) return rc;
-    HIPCHK(hipMemcpyAsync(h->sc[h->cur].mods.p, mods_host, nm, hipMemcpyHostToDevice, h->sc[h->cur].s));
+    const HostSrc src(mods_host, nm);
+    const HostDst dst(out_host, no);
+    HOSTBUF_OK(src);
+    HOSTBUF_OK(dst);
+    HIPCHK(hipMemcpyAsync(h->sc[h->cur].mods.p, src.as<float>(), nm, hipMemcpyHostToDevice, h->sc[h->cur].s));
     if ((rc = launch_trunk(h, (const float*)h->sc[h->cur].mods.p, B, (float*)h->ws_out.p))) return rc;
-    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    HIPCHK(hipMemcpyAsync(dst.as<float>(), h->ws_out.p, no, hipMemcpyDeviceToHost, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
+    dst.finish();
     return 0;
 }
 
@@ -1918,11 +2013,18 @@ static int msiren_forward_latent_impl(msiren_handle h, const float* z_host, int6
     const size_t nz = (size_t)B * h->Z * sizeof(float), no = (size_t)B * h->P * sizeof(float);
     const size_t nm = (size_t)h->L * B * h->H * sizeof(float);
     if ((rc = ensure(h, h->sc[h->cur].latent, nz)) || (rc = ensure(h, h->ws_out, no)) || (rc = ensure(h, h->sc[h->cur].mods, nm))) return rc;
-    HIPCHK(hipMemcpyAsync(h->sc[h->cur].latent.p, z_host, nz, hipMemcpyHostToDevice, h->sc[h->cur].s));
+    const HostSrc src(z_host, nz);
+    const HostDst dst(out_host, no), dst_mods(mods_out_host, nm);
+    HOSTBUF_OK(src);
+    HOSTBUF_OK(dst);
+    HOSTBUF_OK(dst_mods);
+    HIPCHK(hipMemcpyAsync(h->sc[h->cur].latent.p, src.as<float>(), nz, hipMemcpyHostToDevice, h->sc[h->cur].s));
     if ((rc = forward_latent_dev(h, (const float*)h->sc[h->cur].latent.p, B, (float*)h->ws_out.p, (float*)h->sc[h->cur].mods.p))) return rc;
-    HIPCHK(hipMemcpyAsync(out_host, h->ws_out.p, no, hipMemcpyDeviceToHost, h->sc[h->cur].s));
-    if (mods_out_host) HIPCHK(hipMemcpyAsync(mods_out_host, h->sc[h->cur].mods.p, nm, hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    HIPCHK(hipMemcpyAsync(dst.as<float>(), h->ws_out.p, no, hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    if (mods_out_host) HIPCHK(hipMemcpyAsync(dst_mods.as<float>(), h->sc[h->cur].mods.p, nm, hipMemcpyDeviceToHost, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
+    dst.finish();
+    dst_mods.finish();
     return 0;
 }
 
@@ -1958,10 +2060,15 @@ int msiren_encode_tiles(msiren_handle h, const float* tiles_host, int64_t B, flo
     const size_t nt = (size_t)B * h->O * h->O * sizeof(float), nz = (size_t)B * h->Z * sizeof(float);
     auto& c = h->sc[h->cur];
     if ((rc = ensure(h, h->ws_tiles, nt)) || (rc = ensure(h, c.latent, nz))) return rc;
-    HIPCHK(hipMemcpyAsync(h->ws_tiles.p, tiles_host, nt, hipMemcpyHostToDevice, c.s));
+    const HostSrc src(tiles_host, nt);
+    const HostDst dst(z_host, nz);
+    HOSTBUF_OK(src);
+    HOSTBUF_OK(dst);
+    HIPCHK(hipMemcpyAsync(h->ws_tiles.p, src.as<float>(), nt, hipMemcpyHostToDevice, c.s));
     if ((rc = launch_encoder(h, (const float*)h->ws_tiles.p, B, (float*)c.latent.p))) return rc;
-    HIPCHK(hipMemcpyAsync(z_host, c.latent.p, nz, hipMemcpyDeviceToHost, c.s));
+    HIPCHK(hipMemcpyAsync(dst.as<float>(), c.latent.p, nz, hipMemcpyDeviceToHost, c.s));
     HIPCHK(hipStreamSynchronize(c.s));
+    dst.finish();
     return 0;
 }
 
@@ -1973,10 +2080,15 @@ int msiren_modulate(msiren_handle h, const float* z_host, int64_t B, float* mods
     const size_t nz = (size_t)B * h->Z * sizeof(float), nm = (size_t)h->L * B * h->H * sizeof(float);
     auto& c = h->sc[h->cur];
     if ((rc = ensure(h, c.latent, nz)) || (rc = ensure(h, c.mods, nm))) return rc;
-    HIPCHK(hipMemcpyAsync(c.latent.p, z_host, nz, hipMemcpyHostToDevice, c.s));
+    const HostSrc src(z_host, nz);
+    const HostDst dst(mods_host, nm);
+    HOSTBUF_OK(src);
+    HOSTBUF_OK(dst);
+    HIPCHK(hipMemcpyAsync(c.latent.p, src.as<float>(), nz, hipMemcpyHostToDevice, c.s));
     if ((rc = launch_modulator(h, (const float*)c.latent.p, B, (float*)c.mods.p))) return rc;
-    HIPCHK(hipMemcpyAsync(mods_host, c.mods.p, nm, hipMemcpyDeviceToHost, c.s));
+    HIPCHK(hipMemcpyAsync(dst.as<float>(), c.mods.p, nm, hipMemcpyDeviceToHost, c.s));
     HIPCHK(hipStreamSynchronize(c.s));
+    dst.finish();
     return 0;
 }
 
@@ -2037,9 +2149,27 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     // 1.6 + 0.9 MB on this system, tools/host_register_cost.py) and then treated alike: numpy -> numpy 419 -> 358 us.  If the runtime refuses
     // (a range that overlaps a registered one, no memory to lock) the call copies as before.  (HostLock: process-wide, reference-counted.)
     HostLock reg_out, reg_in;  // (released when the call returns: behind sync_all)
-    const bool may_lock = h->host_register && B >= 64;
-    float* out_zc_ = h->zc_out && nchunks == 1 ? (float*)reg_out.device_view(out_host, no, may_lock) : nullptr;
-    const float* in_zc_ = h->zc_in && nchunks == 1 && out_zc_ ? (const float*)reg_in.device_view(tiles_host, nt, may_lock) : nullptr;
+    const bool may_lock = h->host_register && B >= 64 && nchunks == 1 && h->zc_out;
+    // (cut calls ask too: a buffer inside a neighbour's registration keeps that registration alive under this call's copies)
+    void* view_out = reg_out.device_view(out_host, no, may_lock);
+    void* view_in = reg_in.device_view(tiles_host, nt, may_lock && view_out && h->zc_in);
+    // A buffer that is page-locked in part (another thread's call on an overlapping window of the same array; a caller's own partial
+    // hipHostRegister) goes through a page-locked bounce buffer of this call's own: rare, slow (an allocation and a CPU copy), correct.
+    HostBounce bounce_out, bounce_in;
+    float* const out_user = out_host;
+    if (reg_out.partial()) {
+        if (!bounce_out.alloc(no)) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer of %zu bytes", no);
+        out_host = (float*)bounce_out.p;
+        view_out = host_pinned_dev(out_host);
+    }
+    if (reg_in.partial()) {
+        if (!bounce_in.alloc(nt)) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer of %zu bytes", nt);
+        std::memcpy(bounce_in.p, tiles_host, nt);
+        tiles_host = (const float*)bounce_in.p;
+        view_in = host_pinned_dev(tiles_host);
+    }
+    float* out_zc_ = h->zc_out && nchunks == 1 ? (float*)view_out : nullptr;
+    const float* in_zc_ = h->zc_in && nchunks == 1 && out_zc_ ? (const float*)view_in : nullptr;
     float* const out_zc = out_zc_;
     const float* const in_zc = in_zc_;
     float* const out_base = out_zc ? out_zc : (float*)h->ws_out.p;
@@ -2092,6 +2222,7 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     for (int k = pipelined ? nchunks - 1 : 0; k < nchunks && !rc; ++k) download(k);
     h->cur = cur0;
     const int rs = sync_all(h);
+    if (bounce_out.p && !rc && !rs) std::memcpy(out_user, bounce_out.p, no);
     if (h->trace_host) {
         std::fprintf(stderr, "msiren_forward_tiles B=%lld chunks=%d%s (us since entry): ", (long long)B, nchunks, pipelined ? " pipelined" : "");
         for (int k = 0; k < nchunks; ++k) std::fprintf(stderr, "[%lld tiles: h2d %.0f launched %.0f d2h %.0f] ", (long long)plan[k].n, tr_h2d[k], tr_launch[k], tr_d2h[k]);
@@ -2268,10 +2399,15 @@ static int msiren_reconstruct_slices_impl(msiren_handle h, const float* images_h
     const size_t ni = (size_t)n * height * width * sizeof(float);
     const size_t nr = (size_t)n * nV * h->I * nH * h->I * sizeof(float);
     if ((rc = ensure(h, h->ws_in, ni)) || (rc = ensure(h, h->ws_img, nr))) return rc;
-    HIPCHK(hipMemcpyAsync(h->ws_in.p, images_host, ni, hipMemcpyHostToDevice, h->sc[h->cur].s));
+    const HostSrc src(images_host, ni);
+    const HostDst dst(recon_host, nr);
+    HOSTBUF_OK(src);
+    HOSTBUF_OK(dst);
+    HIPCHK(hipMemcpyAsync(h->ws_in.p, src.as<float>(), ni, hipMemcpyHostToDevice, h->sc[h->cur].s));
     if ((rc = reconstruct_on_current_stream(h, (const float*)h->ws_in.p, n, height, width, (float*)h->ws_img.p))) return rc;
-    HIPCHK(hipMemcpyAsync(recon_host, h->ws_img.p, nr, hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    HIPCHK(hipMemcpyAsync(dst.as<float>(), h->ws_img.p, nr, hipMemcpyDeviceToHost, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
+    dst.finish();
     return 0;
 }
 
@@ -2342,7 +2478,9 @@ int msiren_memcpy_h2d(msiren_handle h, void* dst_dev, const void* src_host, size
     if (rc) return rc;
     if (bytes == 0) return 0;
     if ((rc = sync_all(h))) return rc;
-    HIPCHK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, h->sc[h->cur].s));
+    const HostSrc src(src_host, bytes);
+    HOSTBUF_OK(src);
+    HIPCHK(hipMemcpyAsync(dst_dev, src.as<void>(), bytes, hipMemcpyHostToDevice, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
     return 0;
 }
@@ -2352,8 +2490,11 @@ int msiren_memcpy_d2h(msiren_handle h, void* dst_host, const void* src_dev, size
     if (rc) return rc;
     if (bytes == 0) return 0;
     if ((rc = sync_all(h))) return rc;
-    HIPCHK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, h->sc[h->cur].s));
+    const HostDst dst(dst_host, bytes);
+    HOSTBUF_OK(dst);
+    HIPCHK(hipMemcpyAsync(dst.as<void>(), src_dev, bytes, hipMemcpyDeviceToHost, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
+    dst.finish();
     return 0;
 }
 

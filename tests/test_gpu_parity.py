@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden, nerr, rms
-from mri_inr_amd import ModulatedSiren, synthetic as syn
+from mri_inr_amd import ModulatedSiren, _lib, synthetic as syn
 from oracle import siren_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -853,6 +853,97 @@ def test_two_threads_share_one_pageable_input_array():
     from test_gpu_split import make_with_env
     plain = make_with_env(sd, {"MSIREN_HOST_REGISTER": 0}, precision="f16x3")
     assert np.array_equal(plain(shared), ref)
+
+
+def _forward_into(m, x, out):
+    import ctypes
+
+    fp = ctypes.POINTER(ctypes.c_float)
+    assert x.flags.c_contiguous and out.flags.c_contiguous and x.dtype == out.dtype == np.float32
+    _lib.check(m._lib.msiren_forward_tiles(m._h, x.ctypes.data_as(fp), x.shape[0], out.ctypes.data_as(fp)))
+
+
+def test_windows_of_one_array_from_two_threads():
+    """The parallel-for over slices: two handles in two threads work on WINDOWS of one input array and one output array -- adjacent ones
+    (disjoint bytes that share a page at the seam) and input windows that overlap in part.  A window that is page-locked in part by the
+    neighbour's call gets neither a device view nor a runtime copy (hipMemcpy refuses a range that leaves a registration): it goes through
+    a bounce buffer (HostLock::partial).  Every output equals the single-threaded one; no call fails; nothing faults."""
+    import threading
+
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    big_in = np.random.default_rng(78).random((1300, 32, 32), dtype=np.float32)
+    models = [make_model(sd, precision="f16x3") for _ in range(2)]
+    ref = models[0](big_in)
+    big_out = np.zeros((1300, 24, 24), np.float32)
+    errors = []
+
+    def work(i):
+        try:
+            for k in range(36):
+                n = 400 if k % 4 else 100
+                out = big_out[400 * i:400 * i + n]                  # adjacent windows of the shared output array
+                if k % 3 == 0:      # adjacent windows of the input as well
+                    lo_in = 400 * i
+                elif k % 3 == 1:    # input windows that overlap in part: [100, 500) and [300, 700)
+                    lo_in = 100 + 200 * i
+                elif i == 0:        # a wide window (an output buffer of its own) ...
+                    lo_in, n = 0, 800
+                    out = np.empty((n, 24, 24), np.float32)
+                else:               # ... and a moving one inside it
+                    lo_in = 17 * (k % 11)
+                _forward_into(models[i], big_in[lo_in:lo_in + n], out)
+                if not np.array_equal(out, ref[lo_in:lo_in + n]):
+                    errors.append((i, k, lo_in, n, float(np.abs(out - ref[lo_in:lo_in + n]).max())))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors[:5]
+
+
+def test_buffers_page_locked_in_part_go_through_a_bounce_buffer():
+    """Deterministic form of the above: the CALLER page-locks rows [0, 300) of an input and of an output array (hipHostRegister), then calls on
+    rows [200, 600): the first byte of either buffer is page-locked, the last is not.  Same bits as on untouched arrays; fully page-locked
+    and fully pageable windows of the same arrays work as ever."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    m = make_model(sd, precision="f16x3")
+    x = np.random.default_rng(79).random((700, 32, 32), dtype=np.float32)
+    ref = m(x.copy())
+    out = np.zeros((700, 24, 24), np.float32)
+    assert hip.hipHostRegister(ctypes.c_void_p(x.ctypes.data), ctypes.c_size_t(300 * 32 * 32 * 4), ctypes.c_uint(0)) == 0
+    assert hip.hipHostRegister(ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(300 * 24 * 24 * 4), ctypes.c_uint(0)) == 0
+    try:
+        for lo, hi in ((200, 600), (0, 300), (300, 700), (250, 314), (0, 700)):
+            out[:] = 0
+            _forward_into(m, x[lo:hi], out[lo:hi])
+            assert np.array_equal(out[lo:hi], ref[lo:hi]), (lo, hi)
+            assert not out[:lo].any() and not out[hi:].any()
+        # input in part, output pageable; and the other way round
+        o2 = np.empty((400, 24, 24), np.float32)
+        _forward_into(m, x[200:600], o2)
+        assert np.array_equal(o2, ref[200:600])
+        x2 = x[200:600].copy()
+        out[:] = 0
+        _forward_into(m, x2, out[200:600])
+        assert np.array_equal(out[200:600], ref[200:600])
+        # the other synchronous entry points copy through the runtime: the same rule (HostSrc / HostDst)
+        z = m.encoder(x2)
+        assert np.array_equal(m.encoder(x[200:600]), z)
+        d = m.device_array((400, 32, 32)).copy_from(x[200:600])
+        assert np.array_equal(d.numpy(), x2)
+    finally:
+        assert hip.hipHostUnregister(ctypes.c_void_p(x.ctypes.data)) == 0
+        assert hip.hipHostUnregister(ctypes.c_void_p(out.ctypes.data)) == 0
+    out[:] = 0
+    _forward_into(m, x[200:600], out[200:600])
+    assert np.array_equal(out[200:600], ref[200:600])
 
 
 @pytest.mark.parametrize("start", ["0xFFFFF800", "0x7FFFF800"])

@@ -94,5 +94,52 @@ for cfg in ("sine", "morlet", "config5_bf16"):
             print(f"  MISMATCH {cfg}: reconstruct slices {o}..{o + n - 1}", flush=True)
     print(f"{cfg}: {calls} slice-pipeline calls in {secs / 3:.0f} s, {bad} mismatches", flush=True)
     ok = ok and bad == 0
+    if cfg != "sine":
+        continue
+    # host-pointer calls (round 5: buffers page-locked per call and used in place, bounce buffers for windows that are page-locked in
+    # part, the pipelined plan from 2400 tiles): two handles in two threads on random windows of ONE pageable input pool and ONE output pool
+    import ctypes
+    import threading
+
+    fp = ctypes.POINTER(ctypes.c_float)
+    handles = [m, model(cfg)]
+    out_pool = np.zeros((2 * POOL, 24, 24), np.float32)
+    stats = {"calls": 0, "bad": 0}
+    lock = threading.Lock()
+    host_sizes = [1, 47, 48, 63, 64, 65, 100, 400, 401, 800, 1600, 2399, 2400, 3300]
+
+    def host_worker(i):
+        try:
+            host_loop(i)
+        except Exception as e:  # noqa: BLE001
+            with lock:
+                stats["bad"] += 1
+            print(f"  FAILED host call: thread {i}: {e!r}", flush=True)
+
+    def host_loop(i):
+        r = np.random.default_rng(100 + i)
+        t_end = time.time() + secs / 2
+        while time.time() < t_end:
+            b = int(host_sizes[r.integers(len(host_sizes))]) if r.random() < 0.7 else int(r.integers(1, 1200))
+            o = int(r.integers(0, POOL - b + 1))
+            # outputs: a window of the shared pool (this thread's half, so that no two calls write the same bytes) or an array of its own
+            dst = out_pool[i * POOL + o:i * POOL + o + b] if r.random() < 0.7 else np.empty((b, 24, 24), np.float32)
+            _lib.check(handles[i]._lib.msiren_forward_tiles(handles[i]._h, tiles[o:o + b].ctypes.data_as(fp), b, dst.ctypes.data_as(fp)))
+            want = (ref_small if b < 48 else ref)[o:o + b]
+            good = np.array_equal(dst, want)
+            with lock:
+                stats["calls"] += 1
+                if not good:
+                    stats["bad"] += 1
+                    print(f"  MISMATCH host call: thread {i} offset {o} size {b} max|diff| {np.abs(dst - want).max():.3e}", flush=True)
+
+    _lib.check(m._lib.msiren_set_streams(m._h, 1))
+    ths = [threading.Thread(target=host_worker, args=(i,)) for i in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    print(f"{cfg}: {stats['calls']} host-pointer calls from two threads in {secs / 2:.0f} s, {stats['bad']} mismatches", flush=True)
+    ok = ok and stats["bad"] == 0
 print("SOAK OK" if ok else "SOAK FAILED")
 sys.exit(0 if ok else 1)
