@@ -5,7 +5,8 @@ The reference calls scikit-image (``peak_signal_noise_ratio``, ``structural_simi
 scikit-image is not installed in this image, so these are restatements of its published
 definitions (PSNR, NRMSE: closed forms; SSIM: Wang et al. 2004 with skimage's defaults -- 7x7
 uniform window, K1=0.01, K2=0.03, sample covariance, mean over the window-valid interior).
-PARITY UNPINNED for SSIM: no skimage here to generate a fixture; PSNR/NRMSE are exact formulas.
+PARITY UNPINNED for SSIM: no skimage here to generate a fixture (tests/test_host_logic.py checks it against a second,
+independent derivation by explicit windows, oracle/ssim_windows.py); PSNR/NRMSE are exact formulas.
 Host-side, off the hot path.
 """
 

@@ -59,6 +59,24 @@ def test_metrics_closed_forms():
     assert metrics.calculate_ssim(a, b) > metrics.calculate_ssim(a, a + 0.5 * rng.standard_normal(a.shape))
 
 
+def test_ssim_against_an_independent_derivation_by_explicit_windows():
+    """scikit-image is absent (SSIM stays unpinned against the library); oracle/ssim_windows.py derives the same published definition a
+    second way -- explicit 7 x 7 windows that lie fully inside the image, two-pass sample covariance -- and shares no code with
+    metrics.py (uniform_filter + crop, E[xy] - E[x]E[y]).  Agreement to 1e-9 on images of the evaluation's kind and on odd sizes."""
+    from oracle.ssim_windows import ssim_by_windows
+
+    rng = np.random.default_rng(5)
+    for k, shape in enumerate([(320, 320), (64, 48), (7, 7), (9, 31), (33, 8)]):
+        a = syn.make_slice(k, *shape).astype(np.float64) if min(shape) >= 32 else rng.random(shape)
+        b = a + 0.05 * a.max() * rng.standard_normal(shape)
+        if k == 0:
+            a, b = a.astype(np.float32), b.astype(np.float32)      # what the harness hands over
+        dr = metrics.calculate_data_range(a, b)
+        got, want = metrics.calculate_ssim(a, b), ssim_by_windows(a, b, dr)
+        assert abs(got - want) < 1e-9, (shape, got, want)
+        assert 0 < got < 1
+
+
 def test_checkpoint_roundtrip_npz_and_pth(tmp_path):
     sd = syn.make_state_dict(seed=5, dim_hidden=32, num_layers=2, latent_dim=16, siren_patch_size=8)
     for name in ("m.npz", "m.pth"):
