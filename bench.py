@@ -649,6 +649,14 @@ def extras(model, lib, h, _lib, d_img, d_tiles, d_recons, streams, budget_s=0.5)
     eight = np.concatenate([tiles] * 8)
     h2h_8 = host_rate(eight, 8)
     del pin, eight
+    # slice -> slice on host arrays, one synchronous call per slice: the whole of metrics_error's per-slice work (error.py:231-249)
+    img = d_img.numpy()[0]
+    model.reconstruct(img)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        model.reconstruct(img)
+        n += 1
+    h2h_rec = n * 320 * 320 / (time.perf_counter() - t0) / 1e6
     _lib.check(lib.msiren_set_streams(h, streams))
     k = [0]
 
@@ -667,10 +675,11 @@ def extras(model, lib, h, _lib, d_img, d_tiles, d_recons, streams, budget_s=0.5)
         n += 50
     rec = n * 320 * 320 / (time.perf_counter() - t0) / 1e6
     return {"host_to_host_mpixel_s": h2h, "host_to_host_pinned_mpixel_s": h2h_pinned, "host_to_host_8_slices_mpixel_s": h2h_8,
-            "reconstruct_mpixel_s": rec,
+            "reconstruct_mpixel_s": rec, "host_slice_to_slice_mpixel_s": h2h_rec,
             "note": "after the timed region: host numpy -> host numpy through msiren_forward_tiles (PCIe-inclusive), one 320x320 slice per call "
                     "on pageable arrays, on page-locked ones (model.pinned_empty / pin_outputs), 8 slices per call on pageable arrays (the call "
-                    "pipelines itself); and the device-resident slice -> slice pipeline, one slice per call"}
+                    "pipelines itself); the device-resident slice -> slice pipeline, one slice per call; and the same pipeline as one synchronous call "
+                    "per slice on host arrays (msiren_reconstruct_slices: host_slice_to_slice)"}
 
 
 def scaling_selftest(args) -> int:

@@ -172,7 +172,9 @@ MSIREN_API int msiren_forward_tiles_dev(msiren_handle h, const float* tiles_dev,
  * image (Hh,Ww) -> image_to_patches(O,I) (tiling.py:10-64) -> black-patch filter (mean < 1e-10,
  * tiling.py:184-198,244-271) -> ModulatedSiren.forward on the non-black tiles -> zeros re-inserted
  * (tiling.py:274-303) -> weighted overlap-add (tiling.py:67-140) -> recon (nV*I, nH*I).
- * n_slices images of identical size are processed as one batch.  recon_rows/cols may be NULL. */
+ * n_slices images of identical size are processed as one batch.  recon_rows/cols may be NULL.
+ * The host-pointer form page-locks the caller's two buffers for the call (as msiren_forward_tiles does, see msiren_host_alloc below): the
+ * fold stores into recon_host itself, the image arrives by DMA from the locked pages. */
 MSIREN_API int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int64_t n_slices, int32_t height,
                                   int32_t width, float* recon_dev);
 MSIREN_API int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t n_slices, int32_t height,

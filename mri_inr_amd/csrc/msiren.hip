@@ -145,6 +145,7 @@ struct msiren_ctx {
     int half_allowed = 1;      // MSIREN_F16_HALF=0: never use the half-unit instance
     int host_register = 1;     // MSIREN_HOST_REGISTER=0: pageable caller buffers are never page-locked for the duration of a call (A/B knob)
     int zc_out = 1, zc_in = 1;  // MSIREN_ZC_OUT / MSIREN_ZC_IN: kernels write / read page-locked caller buffers in place (A/B knobs)
+    int recon_zc = 5;           // MSIREN_RECON_ZC: host slice -> slice call: 1 = reconstruction stored in place, 2 = image read in place, 4 = image by DMA from locked pages
     int host_pipe_min = 2400;  // MSIREN_HOST_PIPE_MIN: tiles from which a host call cuts itself into chunks (below: one chunk, buffers in place; profiles/r5/04_*)
     int host_first = 112, host_piece = 400;  // MSIREN_HOST_FIRST / MSIREN_HOST_PIECE: tiles in the first / the further chunks of a pipelined host call
     int host_chunks = 0;       // MSIREN_HOST_CHUNKS: chunks a synchronous host call cuts itself into (0 = default)
@@ -1837,6 +1838,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_HOST_REGISTER")) h->host_register = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_ZC_OUT")) h->zc_out = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_ZC_IN")) h->zc_in = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_RECON_ZC")) h->recon_zc = std::atoi(e) & 7;
     if (const char* e = std::getenv("MSIREN_HOST_PIPE_MIN")) h->host_pipe_min = std::max(128, std::atoi(e));
     if (const char* e = std::getenv("MSIREN_HOST_FIRST")) h->host_first = std::max(16, std::atoi(e));
     if (const char* e = std::getenv("MSIREN_HOST_PIECE")) h->host_piece = std::max(64, std::atoi(e));
@@ -2399,15 +2401,35 @@ static int msiren_reconstruct_slices_impl(msiren_handle h, const float* images_h
     const size_t ni = (size_t)n * height * width * sizeof(float);
     const size_t nr = (size_t)n * nV * h->I * nH * h->I * sizeof(float);
     if ((rc = ensure(h, h->ws_in, ni)) || (rc = ensure(h, h->ws_img, nr))) return rc;
-    const HostSrc src(images_host, ni);
-    const HostDst dst(recon_host, nr);
-    HOSTBUF_OK(src);
-    HOSTBUF_OK(dst);
-    HIPCHK(hipMemcpyAsync(h->ws_in.p, src.as<float>(), ni, hipMemcpyHostToDevice, h->sc[h->cur].s));
-    if ((rc = reconstruct_on_current_stream(h, (const float*)h->ws_in.p, n, height, width, (float*)h->ws_img.p))) return rc;
-    HIPCHK(hipMemcpyAsync(dst.as<float>(), h->ws_img.p, nr, hipMemcpyDeviceToHost, h->sc[h->cur].s));
-    HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
-    dst.finish();
+    // Round 5, as in msiren_forward_tiles: the caller's buffers are page-locked for the call's duration (HostLock); the fold stores the
+    // reconstruction straight into the caller's array (recon_zc & 1), the image is fetched by an asynchronous DMA copy from the locked pages
+    // (& 4) or read in place by image_to_patches (& 2: every pixel crosses the link four times -- 32 x 32 tiles at a stride of 16).
+    // tools/host_reconstruct_ab.py.  A buffer that is page-locked in part goes through a bounce buffer.
+    auto& sc = h->sc[h->cur];
+    const int zc = h->host_register ? h->recon_zc : 0;
+    HostLock reg_out, reg_in;
+    HostBounce bounce_out, bounce_in;
+    void* view_out = reg_out.device_view(recon_host, nr, (zc & 1) != 0);
+    void* view_in = reg_in.device_view(images_host, ni, (zc & 6) != 0);
+    float* const recon_user = recon_host;
+    if (reg_out.partial()) {
+        if (!bounce_out.alloc(nr)) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer of %zu bytes", nr);
+        recon_host = (float*)bounce_out.p;
+        view_out = host_pinned_dev(recon_host);
+    }
+    if (reg_in.partial()) {
+        if (!bounce_in.alloc(ni)) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer of %zu bytes", ni);
+        std::memcpy(bounce_in.p, images_host, ni);
+        images_host = (const float*)bounce_in.p;
+        view_in = host_pinned_dev(images_host);
+    }
+    const float* d_img = (zc & 2) && view_in ? (const float*)view_in : (const float*)h->ws_in.p;
+    float* const d_rec = (zc & 1) && view_out ? (float*)view_out : (float*)h->ws_img.p;
+    if (d_img == (const float*)h->ws_in.p) HIPCHK(hipMemcpyAsync(h->ws_in.p, images_host, ni, hipMemcpyHostToDevice, sc.s));
+    if ((rc = reconstruct_on_current_stream(h, d_img, n, height, width, d_rec))) return rc;
+    if (d_rec == (float*)h->ws_img.p) HIPCHK(hipMemcpyAsync(recon_host, h->ws_img.p, nr, hipMemcpyDeviceToHost, sc.s));
+    HIPCHK(hipStreamSynchronize(sc.s));
+    if (bounce_out.p) std::memcpy(recon_user, bounce_out.p, nr);
     return 0;
 }
 

@@ -299,7 +299,7 @@ def test_bench_single_gpu_line_carries_roofline_cpu_baseline_and_extras():
     assert d["collective_fallback"] is False and d["config"]["comm_ranks"] == 1
     ex = d["extra"]
     assert 0 < ex["host_to_host_mpixel_s"] < d["value"] * 1.05   # PCIe-inclusive: never faster than device-resident
-    assert ex["reconstruct_mpixel_s"] > 0
+    assert ex["reconstruct_mpixel_s"] > 0 and 0 < ex["host_slice_to_slice_mpixel_s"] < ex["reconstruct_mpixel_s"] * 1.05
     # every other BASELINE configuration rides in the driver-run line (child runs behind the timed region, never `value`)
     cfgs = ex["configs"]
     want = {"config3_64_slices_n1": "siren_trunk_f16x3w_kernel<0,4>", "config3_64_slices_n1_one_stream": "siren_trunk_f16x3w_kernel<0,4>",

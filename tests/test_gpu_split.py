@@ -284,3 +284,34 @@ def test_by_default_a_large_call_on_a_one_stream_handle_is_one_trunk_launch():
     assert len(ks) == 1 and ks[0]["kernel"] == "siren_trunk_f16x3w_kernel<0,4>" and ks[0]["coords"] == 3300 * 576, ks
     cut = make_with_env(sd, {"MSIREN_SPLIT_MIN": 3200}, precision="f16x3")
     assert np.array_equal(d_out.numpy(), cut(tiles))
+
+
+def test_host_slice_call_in_place_same_bits_as_staged_copies():
+    """msiren_reconstruct_slices (numpy slice -> numpy reconstruction, the reference's metrics_error pattern): since round 5 the caller's
+    buffers are page-locked for the call, the fold stores into the caller's array and the image arrives by DMA from the locked pages
+    (MSIREN_RECON_ZC=5; 0 = staged copies, 3 = both buffers in place).  Same bits in every mode -- masked slices, several slices per call,
+    sizes that are not a multiple of the stride, buffers that are page-locked in part by the caller."""
+    import ctypes
+
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    imgs = np.stack([syn.make_slice(k, 320, 320, brain_mask=bool(k & 1)) for k in range(3)])
+    odd = syn.make_slice(5, 200, 170)
+    staged = make_with_env(sd, {"MSIREN_RECON_ZC": 0}, precision="f16x3")
+    ref, ref_odd = staged.reconstruct(imgs), staged.reconstruct(odd)
+    assert ref.shape == (3, 320, 320) and ref_odd.shape == (208, 176) and np.isfinite(ref).all()
+    for zc in (5, 1, 3, 4):
+        m = make_with_env(sd, {"MSIREN_RECON_ZC": zc}, precision="f16x3")
+        assert np.array_equal(m.reconstruct(imgs), ref), zc
+        assert np.array_equal(m.reconstruct(imgs[1]), ref[1]), zc
+        assert np.array_equal(m.reconstruct(odd), ref_odd), zc
+    # the caller page-locks the first slice of a stack and calls on slices 0..1 and 1..2: the first range is page-locked in part
+    hip = ctypes.CDLL("libamdhip64.so")
+    m = make_model(sd, precision="f16x3")
+    stack = imgs.copy()
+    assert hip.hipHostRegister(ctypes.c_void_p(stack.ctypes.data), ctypes.c_size_t(320 * 320 * 4), ctypes.c_uint(0)) == 0
+    try:
+        assert np.array_equal(m.reconstruct(stack[:2]), ref[:2])
+        assert np.array_equal(m.reconstruct(stack[1:]), ref[1:])
+        assert np.array_equal(m.reconstruct(stack[0]), ref[0])
+    finally:
+        assert hip.hipHostUnregister(ctypes.c_void_p(stack.ctypes.data)) == 0
