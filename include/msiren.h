@@ -17,7 +17,10 @@
  *   - *_dev entry points only enqueue work on the handle's stream: call msiren_sync() (or
  *     msiren_timer_stop()) before reading results;
  *   - one handle = one device + one stream + one weight set; handles are independent and may be
- *     used from different threads (a single handle is not re-entrant).
+ *     used from different threads (a single handle is not re-entrant);
+ *   - threads may hand their handles the same host arrays, or windows of one array that touch or overlap: inputs are only read, and
+ *     the library keeps its per-call page-locking out of the way of a neighbour's call (a window that is page-locked only in part is
+ *     copied through a bounce buffer).  Two calls that WRITE overlapping output ranges race, as any two writers do.
  */
 #ifndef MSIREN_H
 #define MSIREN_H
