@@ -215,11 +215,12 @@ MSIREN_API int msiren_scatter_rows_dev(msiren_handle h, const float* src_dev, co
  * executes in call order.  n = 2: consecutive *_dev FORWARD calls (forward_mods/latent/tiles_dev,
  * reconstruct_slices_dev) alternate between two streams with private scratch, so independent calls
  * overlap on the device (the under-occupied tail of one call's trunk kernel is filled by the next
- * call's kernels).  The caller then must not hand the same output buffer to two consecutive calls,
- * nor feed one call's output to the next, without an msiren_sync() in between.
+ * call's kernels).  n = 3 (round 5): a rotation over three -- call k+2's encoder / Modulator no longer queue behind call k's
+ * trunk, which pays where the trunk OWNS its CUs (config 5: +3.7 %; the default model: +0.1 %).  The caller then must not hand the
+ * same output buffer to n consecutive calls, nor feed one call's output to the next, without an msiren_sync() in between.
  *
- * With n = 1, ONE large msiren_forward_tiles_dev call (>= 3200 tiles of a depth-5 split-fp16 model; environment
- * MSIREN_SPLIT_MIN at msiren_create, 0 = never) overlaps with itself: the encoder + Modulator of most of its batch
+ * With n = 1, ONE large msiren_forward_tiles_dev call (>= MSIREN_SPLIT_MIN tiles of a depth-5 split-fp16 model; environment
+ * variable read at msiren_create, default 0 = never -- behind round 5's one-launch prologue the cut no longer pays) overlaps with itself: the encoder + Modulator of most of its batch
  * (`self.modulator(self.encoder(tiles))`, modulated_siren.py:446) run on the handle's other stream beside the trunk of
  * the first 12 % of the batch, and the trunk of the rest follows on the call's stream.  Results are bit-identical to the
  * uncut call (patches are independent); the call is complete when its stream is. */

@@ -68,9 +68,11 @@ struct DevBuf {
 struct msiren_ctx {
     msiren_config cfg{};
     int H = 0, HP = 0, L = 0, Z = 0, S = 0, P = 0, O = 0, I = 0;
-    // Up to two streams with private scratch: with msiren_set_streams(h, 2) consecutive *_dev forward
+    // Up to three streams with private scratch: with msiren_set_streams(h, 2) consecutive *_dev forward
     // calls alternate between them, so the under-occupied tail of one call's persistent trunk kernel
-    // overlaps the encoder / modulator / trunk start of the next call.
+    // overlaps the encoder / modulator / trunk start of the next call.  Three (round 5): call k+2's prologue no longer queues
+    // behind call k's trunk -- for a trunk that OWNS its CUs (config 5: 1.76 rounds per slice) the next trunk is then ready when the
+    // half-empty last round begins.
     struct StreamCtx {
         hipStream_t s = nullptr;
         DevBuf mods, modpad, latent, patches, keep, rec, queue, feat, plan;
@@ -78,7 +80,7 @@ struct msiren_ctx {
         DevBuf mods2;  // a split call's second part: modulations written on the OTHER stream, read by this stream's trunk
         hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // split call: start of the call -> helper stream; helper's prologue -> this stream
         msiren::PassQueue pq;  // host view of the never-reset pass counter (pass_queue.h)
-    } sc[2];
+    } sc[3];
     int cur = 0, nstreams = 1;
     bool overlap = false;  // a host-pointer call is pipelining itself over both streams
     bool solo = false;     // a synchronous host-pointer call is running on ONE stream: nothing of this handle is to run beside its trunk
@@ -1437,7 +1439,7 @@ bool use_split(msiren_ctx* h, int64_t B) {
 }
 
 int forward_tiles_split(msiren_ctx* h, const float* tiles_dev, int64_t B, float* out_dev) {
-    const int a = h->cur, b = a ^ 1;
+    const int a = h->cur, b = a == 0 ? 1 : 0;
     auto& A = h->sc[a];
     auto& O = h->sc[b];
     int64_t B0 = (B * h->split_pct / 100 + 15) / 16 * 16;
@@ -1664,7 +1666,7 @@ int with_range_fallback(msiren_ctx* h, F&& run) {
 
 // asynchronous forward entry points rotate over the configured streams
 void next_stream(msiren_ctx* h) {
-    if (h->nstreams > 1) h->cur ^= 1;
+    if (h->nstreams > 1) h->cur = (h->cur + 1) % h->nstreams;
 }
 
 // event pairs recorded since the last collection -> totals (the streams have been synchronised by the caller)
@@ -1861,8 +1863,8 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_HOST_SPLIT")) h->host_first_pct = std::max(5, std::min(95, std::atoi(e)));
     declare_expected(h);
     hipError_t e = hipSetDevice(cfg->device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->sc[0].s, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->sc[1].s, hipStreamNonBlocking);
+    for (auto& c : h->sc)
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->status_host, 64, hipHostMallocMapped);
     if (e == hipSuccess) {
         h->status_host[0] = h->status_host[1] = 0;  // [0] f16x3 domain guard
@@ -1895,9 +1897,9 @@ int msiren_destroy(msiren_handle h) {
     float* ptrs[] = {h->d_dump, h->d_s0t512, h->d_s0t, h->d_bias16, h->d_wout16, h->d_grid, h->d_l0, h->d_wp, h->d_bias, h->d_wout, h->d_modw, h->d_modw_rm, h->d_modb, h->d_encw, h->d_foldw, h->d_embias};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
-    DevBuf* bufs[] = {&h->sc[0].cscratch, &h->sc[1].cscratch, &h->sc[0].mods2, &h->sc[1].mods2, &h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img, &h->sc[0].mods, &h->sc[0].modpad, &h->sc[0].latent,
-                      &h->sc[0].patches, &h->sc[0].keep, &h->sc[0].rec, &h->sc[1].mods, &h->sc[1].modpad, &h->sc[1].latent,
-                      &h->sc[1].patches, &h->sc[1].keep, &h->sc[1].rec, &h->sc[0].queue, &h->sc[1].queue, &h->sc[0].feat, &h->sc[1].feat, &h->sc[0].plan, &h->sc[1].plan};
+    std::vector<DevBuf*> bufs = {&h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img};
+    for (auto& c : h->sc)
+        for (DevBuf* b : {&c.cscratch, &c.mods2, &c.mods, &c.modpad, &c.latent, &c.patches, &c.keep, &c.rec, &c.queue, &c.feat, &c.plan}) bufs.push_back(b);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& pr : h->prof_events) {
@@ -2441,7 +2443,7 @@ int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t
 int msiren_set_streams(msiren_handle h, int32_t n) {
     int rc = check(h, false);
     if (rc) return rc;
-    if (n != 1 && n != 2) return fail(MSIREN_E_INVALID, "streams must be 1 or 2, got %d", n);
+    if (n < 1 || n > 3) return fail(MSIREN_E_INVALID, "streams must be 1, 2 or 3, got %d", n);
     if ((rc = sync_all(h))) return rc;
     h->nstreams = n;
     h->cur = 0;

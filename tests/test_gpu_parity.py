@@ -405,17 +405,21 @@ def test_two_stream_pipelining_is_bit_identical():
         ref_img = m.reconstruct(img)
         d_in = [m.device_array(t.shape).copy_from(t) for t in tiles]
         d_out = [m.device_array((t.shape[0], 24, 24)) for t in tiles]
-        _lib.check(m._lib.msiren_set_streams(m._h, 2))
-        for _ in range(3):
-            for a, b, t in zip(d_in, d_out, tiles):
-                _lib.check(m._lib.msiren_forward_tiles_dev(m._h, a.ptr, t.shape[0], b.ptr))
-        m.sync()
-        for r, b in zip(ref, d_out):
-            assert np.array_equal(r, b.numpy())
-        # host-pointer entry points stay self-contained (copies and kernels on one stream) in this mode
-        for _ in range(3):
-            assert np.array_equal(m.reconstruct(img), ref_img)
-            assert np.array_equal(m(tiles[0]), ref[0])
+        for streams in (2, 3):   # (3: round 5 -- the rotation, the cut of a large call and host calls from any position of it)
+            _lib.check(m._lib.msiren_set_streams(m._h, streams))
+            for _ in range(3):
+                for a, b, t in zip(d_in, d_out, tiles):
+                    _lib.check(m._lib.msiren_forward_tiles_dev(m._h, a.ptr, t.shape[0], b.ptr))
+            m.sync()
+            for r, b in zip(ref, d_out):
+                assert np.array_equal(r, b.numpy())
+            # host-pointer entry points stay self-contained (copies and kernels on one stream) in this mode
+            for k in range(4):
+                assert np.array_equal(m.reconstruct(img), ref_img)
+                assert np.array_equal(m(tiles[0]), ref[0])
+                _lib.check(m._lib.msiren_forward_tiles_dev(m._h, d_in[k].ptr, tiles[k].shape[0], d_out[k].ptr))   # (moves the rotation on)
+            m.sync()
+        assert m._lib.msiren_set_streams(m._h, 4) != 0 and m._lib.msiren_set_streams(m._h, 0) != 0
         _lib.check(m._lib.msiren_set_streams(m._h, 1))
         # a large synchronous host call cuts itself in two halves over the two streams (copy overlap):
         # same bits as the whole batch through the device entry point
@@ -571,7 +575,7 @@ def test_config5_batch_invariance_over_pass_shapes():
     ref = orc.siren_forward(sd, mods[:, :3], num_layers=L, activation="sine", residual=True, dtype=np.float64)
     assert nerr(whole[:3].reshape(3, -1), ref) <= 6e-2
     from mri_inr_amd import _lib
-    for streams in (1, 2):
+    for streams in (1, 2, 3):
         _lib.check(m._lib.msiren_set_streams(m._h, streams))
         for b in (1, 2, 7, 57, 58, 129, 256, 257):
             part = m.forward_mods(np.ascontiguousarray(mods[:, :b]))
