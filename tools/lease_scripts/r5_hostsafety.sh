@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5: windows of one array from two threads, buffers page-locked in part (bounce buffer), then the soak with its host-call phase
+# Round 5: windows of one array from two threads, buffers page-locked in part (bounce buffer), then the soak (stream modes 1-3) with its host-call phase
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/r5/hostsafety
 rm -rf $out && mkdir -p $out

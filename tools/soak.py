@@ -51,14 +51,14 @@ for cfg in ("sine", "morlet", "config5_bf16"):
     m.sync()
     ref_small = d_ref.numpy()
     print(f"{cfg}: fused-encoder path vs throughput path: max|diff| {np.abs(ref_small - ref).max():.3e}, rms {np.sqrt(np.mean((ref_small - ref) ** 2)):.3e}", flush=True)
-    outs = [m.device_array((POOL, 24, 24)) for _ in range(4)]
+    outs = [m.device_array((POOL, 24, 24)) for _ in range(6)]
     t_end, it, launches, bad = time.time() + secs, 0, 0, 0
     sizes = [1, 2, 3, 7, 8, 9, 28, 29, 57, 58, 100, 129, 256, 257, 400, 401, 1023, 1024, 1025, 3199, 3200, 3300]
     while time.time() < t_end:
-        streams = int(rng.integers(1, 3))
+        streams = int(rng.integers(1, 4))
         _lib.check(m._lib.msiren_set_streams(m._h, streams))
         pend = []
-        for k in range(4):
+        for k in range(6):
             b = int(sizes[rng.integers(len(sizes))]) if rng.random() < 0.7 else int(rng.integers(1, POOL + 1))
             o = int(rng.integers(0, POOL - b + 1))
             _lib.check(m._lib.msiren_forward_tiles_dev(m._h, d_t.ptr + o * 32 * 32 * 4, b, outs[k].ptr))
@@ -83,7 +83,7 @@ for cfg in ("sine", "morlet", "config5_bf16"):
     alone = np.stack([m.reconstruct(imgs[k]) for k in range(10)])
     t_end, calls, bad = time.time() + secs / 3, 0, 0
     while time.time() < t_end:
-        _lib.check(m._lib.msiren_set_streams(m._h, int(rng.integers(1, 3))))
+        _lib.check(m._lib.msiren_set_streams(m._h, int(rng.integers(1, 4))))
         n = int(rng.integers(1, 7))
         o = int(rng.integers(0, 10 - n + 1))
         _lib.check(m._lib.msiren_reconstruct_slices_dev(m._h, d_i.ptr + o * 320 * 320 * 4, n, 320, 320, d_r.ptr))
