@@ -4,7 +4,7 @@ must equal, bit for bit, the rows of ONE reference run over the whole pool (a ti
 in).  Exercises the pass queues (thousands of launches per handle), every trunk instance's size thresholds (half units, tails,
 2-unit passes, the large-call split), the conditional fp32 launch and the two-stream hand-overs.
 
-    python tools/soak.py [seconds per configuration = 60]
+    python tools/soak.py [seconds per configuration = 60] [sine,morlet,config5_bf16]
 """
 import sys
 import time
@@ -34,7 +34,7 @@ def model(cfg):
 
 
 ok = True
-for cfg in ("sine", "morlet", "config5_bf16"):
+for cfg in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("sine", "morlet", "config5_bf16")):
     m = model(cfg)
     d_t = m.device_array(tiles.shape).copy_from(tiles)
     d_ref = m.device_array((POOL, 24, 24))
