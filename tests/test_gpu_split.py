@@ -315,3 +315,48 @@ def test_host_slice_call_in_place_same_bits_as_staged_copies():
         assert np.array_equal(m.reconstruct(stack[0]), ref[0])
     finally:
         assert hip.hipHostUnregister(ctypes.c_void_p(stack.ctypes.data)) == 0
+
+
+def test_back_to_back_one_stream_calls_across_the_edge_of_the_fp16_domain():
+    """One-stream handle, msiren_forward_tiles_dev calls back to back without a sync; out-of-domain batches and clean ones alternate, other entry
+    points cut in between.  The conditional exact-fp32 launch of call k reads the stream's modulations, which call k+1's prologue overwrites:
+    whatever the library does to get that launch off the critical path (round 5 tried a side stream: slower, profiles/r5/05_*), every buffer
+    must hold the exact-fp32 bits for a flagged batch and the split-fp16 bits otherwise -- here against a second handle used synchronously."""
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    rng = np.random.default_rng(31)
+    clean = rng.random((400, 32, 32), dtype=np.float32)
+    bad = clean.copy()
+    bad[37] *= 3e7                                   # latent ~1e7 -> modulations far beyond 65504
+    small = clean[:7].copy()
+    plain = make_model(sd, precision="f16x3")
+    want = {"clean": plain(clean), "bad": plain(bad), "small": plain(small)}
+    z = plain.encoder(clean[:64])
+    want_latent = plain.forward_latent(z)
+    img = syn.make_slice(4, 320, 320, brain_mask=True)
+    want_img = plain.reconstruct(img)
+    exact = make_model(sd, precision="fp32")
+    assert np.array_equal(want["bad"], exact.forward_mods(np.stack(plain.modulator(plain.encoder(bad)), 0)))   # the whole flagged batch: fp32 bits
+    m = make_model(sd, precision="f16x3")
+    d_in = {k: m.device_array(v.shape).copy_from(v) for k, v in (("clean", clean), ("bad", bad), ("small", small))}
+    d_z, d_img = m.device_array(z.shape).copy_from(z), m.device_array((1, 320, 320)).copy_from(img[None])
+    seq = ["clean", "bad", "clean", "bad", "bad", "small", "clean", "small", "bad", "clean"]
+    outs = [m.device_array((d_in[k].shape[0], 24, 24)) for k in seq]
+    d_lat, d_rec = m.device_array((64, 24, 24)), m.device_array((1, 320, 320))
+    for rep in range(2):
+        for i, k in enumerate(seq):
+            run_dev(m, d_in[k], d_in[k].shape[0], outs[i])
+            if i == 3:    # another entry point in the middle of the run: it orders itself behind the conditional launch that is still aside
+                _lib.check(m._lib.msiren_forward_latent_dev(m._h, d_z.ptr, 64, d_lat.ptr, None))
+            if i == 6:
+                _lib.check(m._lib.msiren_reconstruct_slices_dev(m._h, d_img.ptr, 1, 320, 320, d_rec.ptr))
+        if rep == 0:
+            m.sync()
+    m.sync()
+    for i, k in enumerate(seq):
+        assert np.array_equal(outs[i].numpy(), want[k]), (i, k)
+    assert np.array_equal(d_lat.numpy(), want_latent) and np.array_equal(d_rec.numpy()[0], want_img)
+    # a host call right behind an asynchronous one
+    run_dev(m, d_in["bad"], 400, outs[0])
+    assert np.array_equal(m(clean), want["clean"])
+    m.sync()
+    assert np.array_equal(outs[0].numpy(), want["bad"])
