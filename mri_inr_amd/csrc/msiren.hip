@@ -120,6 +120,12 @@ struct msiren_ctx {
     int* status_dev = nullptr;
     unsigned range_epoch = 0;      // number of the split-fp16 trunk launch in flight (what it writes to its stream's flag word)
     int cond_rerun = 1;            // MSIREN_RANGE_RERUN=0 (A/B knob: what the conditional launch costs): f16x3 launches go unguarded
+    // Synchronous one-chunk msiren_forward_tiles calls (round 5): the host is going to wait for the stream anyway, so the trunk raises its flag in
+    // HOST memory (status_host[8]) and the call looks at it after the wait -- no conditional launch (4.4 us of kernel + a launch gap per call);
+    // a flagged call enqueues the exact-fp32 trunk then and waits once more.  MSIREN_HOST_CHECK=0: the conditional launch, as on the asynchronous API.
+    int host_check = 1;
+    bool host_check_now = false;   // set by the call for the launch_trunk it reaches
+    struct { const float* mods = nullptr; int64_t B = 0; float* out = nullptr; unsigned epoch = 0; bool armed = false; } hc;
     int64_t range_events = 0;      // synchronisations that found the conditional exact-fp32 trunk had run, since create
     float* d_dump = nullptr;       // 256 floats: where lanes of the weight-stationary trunk that have nothing to store write
     int trace_host = 0;            // MSIREN_TRACE_HOST=1: msiren_forward_tiles prints the host-side timeline of the call (stderr)
@@ -910,7 +916,7 @@ int launch_trunk_f16x3w(msiren_ctx* h, const float* mods_dev, int64_t B, float* 
     const msiren::WsSchedule sch = msiren::ws_schedule(units, grid);
     int rc = queue_for_launch(h, sch.npasses(), &p.pass_counter, &p.pass_base);
     if (rc) return rc;
-    p.status = p.pass_counter + 16;  // the stream's flag word, behind the pass counter's line
+    p.status = h->host_check_now ? h->status_dev + 8 : p.pass_counter + 16;  // the stream's flag word, behind the pass counter's line (or the host's)
     p.status_val = (int)h->range_epoch;
     const int lds = msiren::WsLds<4>::total(h->L);
     const bool mor = h->cfg.activation == MSIREN_ACT_MORLET;
@@ -983,7 +989,7 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
         const int grid = (int)std::min<int64_t>(cus, passes);
         int rc = queue_for_launch(h, passes, &p.pass_counter, &p.pass_base);
         if (rc) return rc;
-        p.status = p.pass_counter + 16;  // the stream's flag word, behind the pass counter's line
+        p.status = h->host_check_now ? h->status_dev + 8 : p.pass_counter + 16;  // the stream's flag word, behind the pass counter's line (or the host's)
         p.status_val = (int)h->range_epoch;
         if (half) return queue_launched(h, r4 ? launch_trunk_f16x3h_r<4>(h, p, grid) : launch_trunk_f16x3h_r<3>(h, p, grid));
         return queue_launched(h, r4 ? launch_trunk_f16x3n_r<4>(h, p, grid) : launch_trunk_f16x3n_r<3>(h, p, grid));
@@ -1135,13 +1141,13 @@ int profile_end(msiren_ctx* h, hipEvent_t end_event, int64_t coords) {
 // wrote its number there (a scaled modulation beyond fp16, a NaN / inf).  So the output buffer always holds what the
 // reference's fp32 arithmetic computes (modulated_siren.py:215-233), on the asynchronous API as well; the flag in host memory is
 // informational (msiren_range_events).
-int launch_trunk_f32_cond(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
+int launch_trunk_f32_cond(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev, const int* flag_word = nullptr, unsigned flag_val = 0) {
     auto& c = h->sc[h->cur];
     const int cpp = (h->P + 31) / 32;
     if (B * (int64_t)cpp > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     msiren::TrunkParams p = make_trunk_params(h, mods_dev, h->H, B, out_dev);  // (f16x3 needs H = 256 = HP: no padding of the rows)
-    p.cond = (const int*)c.queue.p + 16;
-    p.cond_val = (int)h->range_epoch;
+    p.cond = flag_word ? flag_word : (const int*)c.queue.p + 16;
+    p.cond_val = (int)(flag_word ? flag_val : h->range_epoch);
     p.items = (int)(B * cpp);
     p.host_flag = h->status_dev;
     const int grid = (int)std::min<int64_t>(p.items, (int64_t)h->num_cus);
@@ -1171,6 +1177,14 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
         if (rc) return rc;
         if ((rc = profile_end(h, e1, B * h->P))) return rc;
         if (!h->cond_rerun) return 0;
+        if (h->host_check_now && !h->x1_ready) {  // (the caller looks at the flag in host memory behind its wait for the stream)
+            h->hc.mods = mods_dev;
+            h->hc.B = B;
+            h->hc.out = out_dev;
+            h->hc.epoch = h->range_epoch;
+            h->hc.armed = true;
+            return 0;
+        }
         if (x1_f16) {  // H = 512: the 64-coordinate exact-fp32 trunk as the conditional launch (its workgroups read the flag word and leave)
             const int chunks = (h->P + 63) / 64;
             if (B * (int64_t)chunks > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
@@ -1851,6 +1865,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_X1_BALANCE")) h->x1_balance = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_X1_GRID")) h->x1_grid = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_RANGE_RERUN")) h->cond_rerun = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_HOST_CHECK")) h->host_check = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_SPLIT_MIN")) h->split_min = std::max<long long>(0, std::atoll(e));
     if (const char* e = std::getenv("MSIREN_LINEAR_TILE_MIN")) { h->lin_tile_min = std::max(0, std::atoi(e)); h->lin_tile_env = true; }
     if (const char* e = std::getenv("MSIREN_SPLIT_PCT")) h->split_pct = std::max(1, std::min(90, std::atoi(e)));
@@ -1867,7 +1882,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->status_host, 64, hipHostMallocMapped);
     if (e == hipSuccess) {
-        h->status_host[0] = h->status_host[1] = 0;  // [0] f16x3 domain guard
+        for (int i = 0; i < 16; ++i) h->status_host[i] = 0;  // [0] f16x3 domain guard (informational), [8] the flag word of synchronous host calls
         e = hipHostGetDevicePointer((void**)&h->status_dev, (void*)h->status_host, 0);
     }
 
@@ -2186,9 +2201,10 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     struct Restore {  // the launchers address the stream through h->cur, the trunk through h->trunk_force, the prologue's ring through h->em_beside
         msiren_ctx* h;
         int cur;
-        ~Restore() { h->cur = cur; h->trunk_force = 0; h->em_beside = false; h->overlap = false; h->no_split = false; h->trunk_after = nullptr; }
+        ~Restore() { h->cur = cur; h->trunk_force = 0; h->em_beside = false; h->overlap = false; h->no_split = false; h->trunk_after = nullptr; h->host_check_now = false; h->hc.armed = false; }
     } restore{h, cur0};
     h->no_split = pipelined;
+    h->host_check_now = h->host_check && nchunks == 1 && !use_split(h, B);
     auto download = [&](int k) {
         const Chunk& c = plan[k];
         tr_d2h[k] = us();
@@ -2225,7 +2241,17 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     }
     for (int k = pipelined ? nchunks - 1 : 0; k < nchunks && !rc; ++k) download(k);
     h->cur = cur0;
-    const int rs = sync_all(h);
+    int rs = sync_all(h);
+    if (!rc && !rs && h->hc.armed && (unsigned)h->status_host[8] == h->hc.epoch) {
+        // the trunk met a modulation outside the fp16 domain: the batch once more on the exact-fp32 trunk (the conditional kernel, its
+        // condition pointed at the word that has just been read), the download once more if there is one
+        h->hc.armed = false;
+        h->cur = plan[0].stream;
+        rc = launch_trunk_f32_cond(h, h->hc.mods, h->hc.B, h->hc.out, h->status_dev + 8, h->hc.epoch);
+        if (!rc) download(0);
+        h->cur = cur0;
+        rs = sync_all(h);
+    }
     if (bounce_out.p && !rc && !rs) std::memcpy(out_user, bounce_out.p, no);
     if (h->trace_host) {
         std::fprintf(stderr, "msiren_forward_tiles B=%lld chunks=%d%s (us since entry): ", (long long)B, nchunks, pipelined ? " pipelined" : "");

@@ -360,3 +360,45 @@ def test_back_to_back_one_stream_calls_across_the_edge_of_the_fp16_domain():
     assert np.array_equal(m(clean), want["clean"])
     m.sync()
     assert np.array_equal(outs[0].numpy(), want["bad"])
+
+
+def test_synchronous_host_call_checks_the_domain_flag_on_the_host():
+    """A one-chunk msiren_forward_tiles call waits for its stream anyway: since round 5 its trunk raises the out-of-domain flag in host memory and
+    the call looks at it after the wait -- no conditional launch per call; a flagged call runs the exact-fp32 trunk then (and downloads again
+    where it copies).  Same buffers as with the conditional launch (MSIREN_HOST_CHECK=0): in place (400 tiles), with copies (48 tiles), on
+    page-locked arrays; clean calls before and after a flagged one keep their split-fp16 bits; the event counter counts."""
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    rng = np.random.default_rng(33)
+    clean = rng.random((400, 32, 32), dtype=np.float32)
+    bad = clean.copy()
+    bad[37] *= 3e7
+    exact = make_model(sd, precision="fp32")
+    old = make_with_env(sd, {"MSIREN_HOST_CHECK": 0}, precision="f16x3")
+    mods_of = lambda x: np.stack(old.modulator(old.encoder(x)), 0)
+    want_clean, want_bad, want_bad48 = old(clean), exact.forward_mods(mods_of(bad)), exact.forward_mods(mods_of(bad[:48]))
+    assert np.array_equal(old(bad), want_bad) and np.array_equal(old(bad[:48]), want_bad48)
+    m = make_model(sd, precision="f16x3")
+    def events(mm):
+        import ctypes as C
+
+        n = C.c_int64()
+        _lib.check(mm._lib.msiren_range_events(mm._h, C.byref(n)))
+        return n.value
+
+    e0 = events(m)
+    assert np.array_equal(m(clean), want_clean) and events(m) == e0
+    assert np.array_equal(m(bad), want_bad) and events(m) == e0 + 1            # in place
+    assert np.array_equal(m(clean), want_clean) and events(m) == e0 + 1
+    assert np.array_equal(m(bad[:48]), want_bad48) and events(m) == e0 + 2     # copies: downloaded again
+    assert np.array_equal(m(clean[:48]), want_clean[:48])
+    pin = m.pinned_empty(bad.shape)
+    pin[...] = bad
+    m.pin_outputs(True)
+    assert np.array_equal(m(pin), want_bad) and events(m) == e0 + 3
+    m.pin_outputs(False)
+    # asynchronous calls keep the conditional launch; a host call right behind one
+    d_in, d_out = m.device_array(bad.shape).copy_from(bad), m.device_array((400, 24, 24))
+    run_dev(m, d_in, 400, d_out)
+    assert np.array_equal(m(clean), want_clean)
+    m.sync()
+    assert np.array_equal(d_out.numpy(), want_bad)
