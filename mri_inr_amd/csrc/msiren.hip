@@ -119,6 +119,7 @@ struct msiren_ctx {
     volatile int* status_host = nullptr;
     int* status_dev = nullptr;
     unsigned range_epoch = 0;      // number of the split-fp16 trunk launch in flight (what it writes to its stream's flag word)
+    int tiling_fused = 1;          // MSIREN_TILING_FUSED: 0 = image_to_patches, black_flags, compact_flags and the pass counter's reset as separate stream operations, 1 = one launch in synchronous host calls, 2 = always
     int cond_rerun = 1;            // MSIREN_RANGE_RERUN=0 (A/B knob: what the conditional launch costs): f16x3 launches go unguarded
     // Synchronous one-chunk msiren_forward_tiles calls (round 5): the host is going to wait for the stream anyway, so the trunk raises its flag in
     // HOST memory (status_host[8]) and the call looks at it after the wait -- no conditional launch (4.4 us of kernel + a launch gap per call);
@@ -812,17 +813,23 @@ msiren::TrunkParams make_trunk_params(msiren_ctx* h, const float* mods, int stri
 // one atomicAdd on the counter, so a launch of n passes advances it by n: the counter is never reset, the
 // host hands each launch the value it will find (no memset node per call).  The host value moves only once
 // the launch has been accepted (queue_launched); a failure in between leaves it where the device counter is.
+int ensure_queue(msiren_ctx* h) {
+    auto& c = h->sc[h->cur];
+    if (c.queue.p) return 0;
+    int rc = ensure(h, c.queue, 256);
+    if (rc) return rc;
+    // test knob: start the never-reset counter just below 2^32 (or 2^31) to exercise its wrap-around
+    const unsigned start = h->queue_start;
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c.queue.p, (int)start, 16, c.s));          // [0..15]: the pass counter's line
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)((int*)c.queue.p + 16), 0, 48, c.s));     // [16]: the domain guard's flag word; [32]: the slice pipeline's ticket counter
+    c.pq.reset(start);
+    return 0;
+}
+
 int queue_for_launch(msiren_ctx* h, int64_t npasses, int** counter, unsigned* base) {
     auto& c = h->sc[h->cur];
-    if (!c.queue.p) {
-        int rc = ensure(h, c.queue, 256);
-        if (rc) return rc;
-        // test knob: start the never-reset counter just below 2^32 (or 2^31) to exercise its wrap-around
-        const unsigned start = h->queue_start;
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)c.queue.p, (int)start, 16, c.s));          // [0..15]: the pass counter's line
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)((int*)c.queue.p + 16), 0, 48, c.s));     // [16]: the domain guard's flag word
-        c.pq.reset(start);
-    }
+    int rc = ensure_queue(h);
+    if (rc) return rc;
     *counter = (int*)c.queue.p;
     *base = c.pq.begin(npasses);
     return 0;
@@ -835,10 +842,10 @@ int queue_launched(msiren_ctx* h, int rc) {
 }
 
 // After a launch whose number of passes only the device knows (black patches skipped): reset the counter.
-int queue_reset_after_plan_launch(msiren_ctx* h) {
+int queue_reset_after_plan_launch(msiren_ctx* h, bool by_the_next_kernel = false) {
     auto& c = h->sc[h->cur];
     if (!c.queue.p) return 0;
-    HIPCHK(hipMemsetAsync(c.queue.p, 0, 4, c.s));
+    if (!by_the_next_kernel) HIPCHK(hipMemsetAsync(c.queue.p, 0, 4, c.s));  // (else: weighted_fold_kernel's reset_word)
     c.pq.reset(0);
     return 0;
 }
@@ -1865,6 +1872,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_X1_BALANCE")) h->x1_balance = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_X1_GRID")) h->x1_grid = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_RANGE_RERUN")) h->cond_rerun = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSIREN_TILING_FUSED")) h->tiling_fused = std::max(0, std::min(2, std::atoi(e)));
     if (const char* e = std::getenv("MSIREN_HOST_CHECK")) h->host_check = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_SPLIT_MIN")) h->split_min = std::max<long long>(0, std::atoll(e));
     if (const char* e = std::getenv("MSIREN_LINEAR_TILE_MIN")) { h->lin_tile_min = std::max(0, std::atoi(e)); h->lin_tile_env = true; }
@@ -2299,7 +2307,7 @@ int msiren_weighted_fold_dev(msiren_handle h, const float* tiles_dev, int64_t n,
     if (n == 0) return 0;
     const int64_t total = n * nV * h->I * (int64_t)nH * h->I;
     hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->sc[h->cur].s,
-                       tiles_dev, h->d_foldw, recon_dev, nullptr, nullptr, n, nV, nH, h->S, h->I, (h->S - h->I) / 2);
+                       tiles_dev, h->d_foldw, recon_dev, nullptr, nullptr, n, nV, nH, h->S, h->I, (h->S - h->I) / 2, (int*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2347,15 +2355,18 @@ int msiren_patches_to_image_dev(msiren_handle h, const float* tiles_dev, int64_t
     if (n == 0) return 0;
     const int64_t total = n * nV * h->I * (int64_t)nH * h->I;
     hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->sc[h->cur].s,
-                       tiles_dev, nullptr, image_dev, nullptr, nullptr, n, nV, nH, h->O, h->I, (h->O - h->I) / 2);
+                       tiles_dev, nullptr, image_dev, nullptr, nullptr, n, nV, nH, h->O, h->I, (h->O - h->I) / 2, (int*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 // filter -> model -> reintegrate -> weighted fold on tiles that are already on the device (CURRENT stream)
-static int reconstruct_tiles_on_current_stream(msiren_handle h, const float* patches, int64_t n, int32_t nV, int32_t nH, float* recon_dev) {
+// `images_dev` given: `patches` is scratch that image_to_patches fills; null: `patches` are the caller's tiles
+static int reconstruct_tiles_on_current_stream(msiren_handle h, const float* images_dev, int32_t height, int32_t width, float* patches_rw, const float* patches_ro,
+                                               int64_t n, int32_t nV, int32_t nH, float* recon_dev) {
     int rc;
     const int64_t NP = n * nV * nH;
+    if (NP > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "too many patches for one call: %lld", (long long)NP);
     if ((rc = ensure(h, h->sc[h->cur].keep, (size_t)(NP + 64) * sizeof(int)))) return rc;
     if ((rc = ensure(h, h->sc[h->cur].rec, (size_t)NP * h->P * sizeof(float)))) return rc;
     if ((rc = ensure(h, h->sc[h->cur].latent, (size_t)NP * h->Z * sizeof(float)))) return rc;
@@ -2369,19 +2380,36 @@ static int reconstruct_tiles_on_current_stream(msiren_handle h, const float* pat
     if ((rc = ensure(h, h->sc[h->cur].plan, (size_t)(2 + 2 * NP) * sizeof(int)))) return rc;
     int* plan = (int*)h->sc[h->cur].plan.p;
     hipStream_t st = h->sc[h->cur].s;
-    hipLaunchKernelGGL(msiren::black_flags_kernel, dim3((unsigned)NP), dim3(256), 0, st, patches, black, h->O * h->O);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(msiren::compact_flags_kernel, dim3(1), dim3(256), 0, st, black, (int)NP, (h->P + 31) / 32, plan);
-    HIPCHK(hipGetLastError());
+    const float* patches = images_dev ? patches_rw : patches_ro;
+    const int pad = (h->O - h->I) / 2;
+    // Round 5, synchronous host calls: tiling + flags + plan as ONE launch and the pass counter's reset inside the fold: 10 stream operations
+    // per slice -> 7.  The host enqueues into an idle stream there, so every launch saved is ~3 us (370 against 379 us per slice, 263 against
+    // 272 masked); back-to-back asynchronous calls run from a full queue and lose 0.6-1.5 % to the fused kernel's 400 device-wide fences, so
+    // they keep the separate kernels (profiles/r5/13_*).  Same bits either way (the flag is summed in the same order); MSIREN_TILING_FUSED=0 / 2:
+    // never / always.
+    const bool fused = (h->tiling_fused == 2 || (h->tiling_fused == 1 && h->solo)) && (images_dev || patches_rw);
+    if (fused) {
+        if ((rc = ensure_queue(h))) return rc;
+        msiren::TilingPlanParams tp{images_dev, patches_rw, black, plan, (unsigned*)h->sc[h->cur].queue.p + 32, (int)n, height, width, nV, nH, h->O, h->I, pad, (int)NP, (h->P + 31) / 32};
+        hipLaunchKernelGGL(msiren::patches_flags_plan_kernel, dim3((unsigned)NP), dim3(256), 0, st, tp);
+        HIPCHK(hipGetLastError());
+    } else {
+        if (images_dev && (rc = msiren_image_to_patches_dev(h, images_dev, n, height, width, patches_rw))) return rc;
+        hipLaunchKernelGGL(msiren::black_flags_kernel, dim3((unsigned)NP), dim3(256), 0, st, patches, black, h->O * h->O);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(msiren::compact_flags_kernel, dim3(1), dim3(256), 0, st, black, (int)NP, (h->P + 31) / 32, plan);
+        HIPCHK(hipGetLastError());
+    }
     h->plan = plan;
     rc = launch_encoder_modulator(h, patches, NP, (float*)h->sc[h->cur].latent.p, (float*)h->sc[h->cur].mods.p);
     if (!rc) rc = launch_trunk(h, (const float*)h->sc[h->cur].mods.p, NP, rec);
     h->plan = nullptr;
     if (rc) return rc;
-    if ((rc = queue_reset_after_plan_launch(h))) return rc;
+    if ((rc = queue_reset_after_plan_launch(h, fused))) return rc;
     const int64_t total = n * nV * h->I * (int64_t)nH * h->I;
     hipLaunchKernelGGL(msiren::weighted_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       rec, h->d_foldw, recon_dev, black, plan + 2 + NP, n, nV, nH, h->S, h->I, (h->S - h->I) / 2);
+                       rec, h->d_foldw, recon_dev, black, plan + 2 + NP, n, nV, nH, h->S, h->I, (h->S - h->I) / 2,
+                       fused && h->sc[h->cur].queue.p ? (int*)h->sc[h->cur].queue.p : nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2395,10 +2423,14 @@ static int reconstruct_on_current_stream(msiren_handle h, const float* images_de
     int32_t nV, nH;
     if ((rc = msiren_recon_shape(h, height, width, &nV, &nH))) return rc;
     const int64_t NP = n * nV * nH;
+    const int padr = (h->O - h->I) / 2;
+    const int vpad = (h->I - height % h->I) % h->I, hpad = (h->I - width % h->I) % h->I;
+    // torch's reflect padding requires pad < dim (F.pad raises otherwise): the rule of msiren_image_to_patches_dev
+    if (padr + vpad >= height || padr + hpad >= width)
+        return fail(MSIREN_E_INVALID, "image %dx%d is too small for reflect padding of %d/%d", height, width, padr + vpad, padr + hpad);
     if ((rc = ensure(h, h->sc[h->cur].patches, (size_t)NP * h->O * h->O * sizeof(float)))) return rc;
     float* patches = (float*)h->sc[h->cur].patches.p;
-    if ((rc = msiren_image_to_patches_dev(h, images_dev, n, height, width, patches))) return rc;
-    return reconstruct_tiles_on_current_stream(h, patches, n, nV, nH, recon_dev);
+    return reconstruct_tiles_on_current_stream(h, images_dev, height, width, patches, nullptr, n, nV, nH, recon_dev);
 }
 
 int msiren_reconstruct_tiles_dev(msiren_handle h, const float* tiles_dev, int64_t n, int32_t nV, int32_t nH, float* recon_dev) {
@@ -2408,7 +2440,7 @@ int msiren_reconstruct_tiles_dev(msiren_handle h, const float* tiles_dev, int64_
     if (n < 0 || nV < 1 || nH < 1 || (n > 0 && (!tiles_dev || !recon_dev))) return fail(MSIREN_E_INVALID, "bad arguments");
     if (h->O != 32) return fail(MSIREN_E_INVALID, "the custom encoder is hard-wired to 32x32 tiles, outer_patch_size=%d", h->O);
     if (n == 0) return 0;
-    return reconstruct_tiles_on_current_stream(h, tiles_dev, n, nV, nH, recon_dev);
+    return reconstruct_tiles_on_current_stream(h, nullptr, 0, 0, nullptr, tiles_dev, n, nV, nH, recon_dev);
 }
 
 int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int64_t n, int32_t height, int32_t width, float* recon_dev) {

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void black_flags_kernel(const float* __restric
 // which never evaluates the model on a black tile -- without the host learning the count.
 // One workgroup of 256 threads (one wave per SIMD, few registers: it has to fit beside a resident trunk
 // workgroup of the other stream); n is a few hundred per slice.
-__global__ __launch_bounds__(256) void compact_flags_kernel(const int* __restrict__ flags, int n, int units_per_patch, int* __restrict__ plan) {
+__device__ __forceinline__ void compact_flags_block(const int* __restrict__ flags, int n, int units_per_patch, int* __restrict__ plan) {
     __shared__ int wsum[4];
     __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,6 +96,62 @@ __global__ __launch_bounds__(256) void compact_flags_kernel(const int* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void compact_flags_kernel(const int* __restrict__ flags, int n, int units_per_patch, int* __restrict__ plan) {
+    compact_flags_block(flags, n, units_per_patch, plan);
+}
+
+// image_to_patches + black_flags + compact_flags in ONE launch (round 5: the slice pipeline is a chain of small dependent launches in
+// front of the trunk, each worth ~2.5 us of kernel and ~2 us of gap).  One workgroup per patch: gather it from the image (img == null:
+// the patches are given), sum it in black_flags_kernel's order (the same flag, bit for bit), take a ticket; the workgroup that draws the
+// last ticket -- every flag has been written and fenced by then -- builds the plan (compact_flags_block) and puts the ticket counter back.
+struct TilingPlanParams {
+    const float* img;   // (n, Hh, Ww) or null
+    float* patches;     // (NP, O, O): written when img is given, read otherwise
+    int* flags;         // (NP)
+    int* plan;          // (2 + 2 NP)
+    unsigned* ticket;   // zero between launches
+    int n, Hh, Ww, nV, nH, O, I, pad, NP, units_per_patch;
+};
+__global__ __launch_bounds__(256) void patches_flags_plan_kernel(TilingPlanParams p) {
+    __shared__ float red[4];
+    __shared__ int last;
+    const int b = blockIdx.x, tid = threadIdx.x, elems = p.O * p.O;
+    float* dst = p.patches + (size_t)b * elems;
+    float s = 0.f;
+    if (p.img) {
+        const int per = p.nV * p.nH, sl = b / per, r = b - sl * per, v = r / p.nH, hh = r - v * p.nH;
+        const float* im = p.img + (size_t)sl * p.Hh * p.Ww;
+        for (int i = tid; i < elems; i += 256) {
+            const int y = i / p.O, x = i - y * p.O;
+            int sy = v * p.I + y - p.pad, sx = hh * p.I + x - p.pad;
+            sy = sy < 0 ? -sy : sy;
+            sy = sy >= p.Hh ? 2 * (p.Hh - 1) - sy : sy;
+            sx = sx < 0 ? -sx : sx;
+            sx = sx >= p.Ww ? 2 * (p.Ww - 1) - sx : sx;
+            const float val = im[(size_t)sy * p.Ww + sx];
+            dst[i] = val;
+            s += val;
+        }
+    } else {
+        for (int i = tid; i < elems; i += 256) s += dst[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)elems;
+        p.flags[b] = mean < 1e-10f ? 1 : 0;
+        __threadfence();  // the flag is visible device-wide before the ticket is
+        last = atomicAdd(p.ticket, 1u) == (unsigned)(p.NP - 1);
+    }
+    __syncthreads();
+    if (!last) return;  // workgroup-uniform
+    __threadfence();      // (acquire: the other workgroups' flags)
+    compact_flags_block(p.flags, p.NP, p.units_per_patch, p.plan);
+    if (tid == 0) *p.ticket = 0u;
+}
+
 // filter_and_remember_black_patches' `patches[non_black_indices]` (tiling.py:268) and reintegrate_black_patches' copy-back
 // (tiling.py:294-301) as row copies through an index list: gather: dst[j] = src[idx[j]]; scatter: dst[idx[j]] = src[j]
 // (the caller zero-fills dst first: black rows stay zeros).  One workgroup per row.
@@ -111,9 +167,13 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
 // stride I, padding `pad`.  Black patches (flags[b] != 0) contribute zeros with their full weight,
 // as reintegrate_black_patches + fold do in the reference (tiling.py:287-301, :117-118).
 // `pos` (optional): tiles holds the kept patches only, patch b at row pos[b] (compact_flags_kernel).
+// `reset_word` (optional): set to 0 by the first thread -- the pass counter of a launch whose number of passes only the device knew
+// (one memset node less behind the trunk).
 __global__ void weighted_fold_kernel(const float* __restrict__ tiles, const float* __restrict__ w, float* __restrict__ recon,
-                                     const int* __restrict__ flags, const int* __restrict__ pos, int64_t n, int nV, int nH, int S, int I, int pad) {
+                                     const int* __restrict__ flags, const int* __restrict__ pos, int64_t n, int nV, int nH, int S, int I, int pad,
+                                     int* __restrict__ reset_word = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (reset_word && i == 0) *reset_word = 0;
     const int OH = nV * I, OW = nH * I;
     if (i >= n * OH * (int64_t)OW) return;
     const int64_t s = i / ((int64_t)OH * OW);

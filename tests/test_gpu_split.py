@@ -402,3 +402,43 @@ def test_synchronous_host_call_checks_the_domain_flag_on_the_host():
     assert np.array_equal(m(clean), want_clean)
     m.sync()
     assert np.array_equal(d_out.numpy(), want_bad)
+
+
+def test_fused_tiling_flags_plan_same_bits_as_the_separate_kernels():
+    """Round 5: image_to_patches + black_flags + compact_flags as one launch (the workgroup that draws the last ticket builds the plan) and the
+    pass counter's reset inside the fold.  MSIREN_TILING_FUSED=0 = the separate kernels: the same reconstruction bit for bit -- masked and
+    unmasked slices, several per call, odd sizes, all-black and no-black inputs, many calls in a row (the ticket counter is put back each time),
+    one and two streams."""
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    imgs = np.stack([syn.make_slice(k, 320, 320, brain_mask=bool(k % 3)) for k in range(6)])
+    odd = syn.make_slice(9, 200, 170, brain_mask=True)
+    black = np.zeros((320, 320), np.float32)
+    sep = make_with_env(sd, {"MSIREN_TILING_FUSED": 0}, precision="f16x3")
+    m = make_with_env(sd, {"MSIREN_TILING_FUSED": 2}, precision="f16x3")      # (2: on the asynchronous API as well; the default fuses in host calls only)
+    want, want_odd = sep.reconstruct(imgs), sep.reconstruct(odd)
+    assert np.array_equal(make_model(sd, precision="f16x3").reconstruct(imgs), want)
+    assert np.array_equal(sep.reconstruct(black), np.zeros_like(black))
+    for rep in range(3):
+        assert np.array_equal(m.reconstruct(imgs), want)
+        assert np.array_equal(m.reconstruct(odd), want_odd)
+        assert np.array_equal(m.reconstruct(black), np.zeros_like(black))
+        for k in range(6):
+            assert np.array_equal(m.reconstruct(imgs[k]), want[k]), k
+    # asynchronous calls back to back on one and two streams, forward calls in between (they share the pass counter the fold resets)
+    tiles = np.random.default_rng(41).random((100, 32, 32), dtype=np.float32)
+    want_t = sep(tiles)
+    d_i = m.device_array(imgs.shape).copy_from(imgs)
+    d_t, d_to = m.device_array(tiles.shape).copy_from(tiles), [m.device_array((100, 24, 24)) for _ in range(4)]
+    for streams in (1, 2, 3):
+        _lib.check(m._lib.msiren_set_streams(m._h, streams))
+        d_r = [m.device_array((1, 320, 320)) for _ in range(12)]
+        for j in range(12):
+            _lib.check(m._lib.msiren_reconstruct_slices_dev(m._h, d_i.ptr + (j % 6) * 320 * 320 * 4, 1, 320, 320, d_r[j].ptr))
+            if j % 3 == 1:
+                run_dev(m, d_t, 100, d_to[j // 3])
+        m.sync()
+        for j in range(12):
+            assert np.array_equal(d_r[j].numpy()[0], want[j % 6]), (streams, j)
+        for o in d_to:
+            assert np.array_equal(o.numpy(), want_t)
+    _lib.check(m._lib.msiren_set_streams(m._h, 1))

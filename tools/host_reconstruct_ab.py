@@ -10,15 +10,16 @@ from mri_inr_amd import ModulatedSiren, _lib, synthetic as syn  # noqa: E402
 sd = syn.make_state_dict(seed=7, trained_like=True)
 for mask in (False, True):
     img = syn.make_slice(3, 320, 320, brain_mask=mask)
-    for name, env in (("host call (default: 5)", {}), ("host call, MSIREN_RECON_ZC=0 (staged copies)", {"MSIREN_RECON_ZC": "0"}),
-                      ("host call, MSIREN_RECON_ZC=1 (out in place)", {"MSIREN_RECON_ZC": "1"}), ("host call, MSIREN_RECON_ZC=3 (both in place)", {"MSIREN_RECON_ZC": "3"}),
-                      ("host call, MSIREN_RECON_ZC=4 (image by DMA)", {"MSIREN_RECON_ZC": "4"}), ("host call, MSIREN_RECON_ZC=5", {"MSIREN_RECON_ZC": "5"}),
-                      ("device call + sync", None)):
+    for name, env in (("host call (default)", {}), ("host call, MSIREN_TILING_FUSED=0", {"MSIREN_TILING_FUSED": "0"}),
+                      ("host call, MSIREN_RECON_ZC=0 (staged copies)", {"MSIREN_RECON_ZC": "0"}),
+                      ("device call + sync", None), ("device call + sync, MSIREN_TILING_FUSED=0", {"MSIREN_TILING_FUSED": "0", "dev": "1"})):
+        os.environ.pop("MSIREN_TILING_FUSED", None)
         os.environ.pop("MSIREN_RECON_ZC", None)
-        os.environ.update(env or {})
+        dev = env is None or "dev" in env
+        os.environ.update({k: v for k, v in (env or {}).items() if k != "dev"})
         m = ModulatedSiren(2, 256, 1, 5, 256, 1.0, 30.0, True, 0.1, True, "custom", None, 32, 16, 24, "cuda", "sine")
         m.load_state_dict(sd); m.to("cuda")
-        if env is None:
+        if dev:
             d_i = m.device_array((1, 320, 320)).copy_from(img[None])
             d_o = m.device_array((1, 320, 320))
             def call():
