@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256, 5) void encoder_kernel(EncoderParams p, const 
     __shared__ float a3[64];
     const int tid = threadIdx.x;
     if (p.plan && (int)blockIdx.x >= p.plan[0]) return;  // workgroup-uniform
-    const float* tile = tiles + (size_t)(p.plan ? p.plan[2 + blockIdx.x] : (int)blockIdx.x) * 1024;
+    const float* tile = enc_tile(p, tiles, p.plan ? p.plan[2 + blockIdx.x] : (int)blockIdx.x);
 
     for (int i = tid; i < 33 * 33; i += 256) {
         const int y = i / 33, x = i - y * 33;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 5) void encoder_conv_kernel(EncoderParams p, c
     __shared__ float a1[16 * 2 * PLANE];     // [channel][column parity][row][column >> 1]
     const int tid = threadIdx.x;
     if (p.plan && (int)blockIdx.x >= p.plan[0]) return;  // workgroup-uniform
-    const float* tile = tiles + (size_t)(p.plan ? p.plan[2 + blockIdx.x] : (int)blockIdx.x) * 1024;
+    const float* tile = enc_tile(p, tiles, p.plan ? p.plan[2 + blockIdx.x] : (int)blockIdx.x);
 
     for (int i = tid; i < 33 * 33; i += 256) {
         const int y = i / 33, x = i - y * 33;

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, 5) void encoder_conv_f16x3_kernel(EncoderParam
     __shared__ float wmax[8];
     const int tid = threadIdx.x;
     if (p.plan && (int)blockIdx.x >= p.plan[0]) return;  // workgroup-uniform
-    const float* tile = tiles + (size_t)(p.plan ? p.plan[2 + blockIdx.x] : (int)blockIdx.x) * 1024;
+    const float* tile = enc_tile(p, tiles, p.plan ? p.plan[2 + blockIdx.x] : (int)blockIdx.x);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     em_f4 o0, o1;  // the thread's eight features (before scale and split)
 

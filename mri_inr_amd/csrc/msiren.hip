@@ -118,6 +118,8 @@ struct msiren_ctx {
     // f16x3 domain guard: a word in host memory the trunk kernels set when a scaled modulation does not fit fp16
     volatile int* status_host = nullptr;
     int* status_dev = nullptr;
+    float* seam_host = nullptr;    // two tiles of page-locked scratch: the first / last tile of a host call whose tiles are read in place (EncoderParams::seam)
+    float* seam_dev = nullptr;
     unsigned range_epoch = 0;      // number of the split-fp16 trunk launch in flight (what it writes to its stream's flag word)
     int tiling_fused = 1;          // MSIREN_TILING_FUSED: 0 = image_to_patches, black_flags, compact_flags and the pass counter's reset as separate stream operations, 1 = one launch in synchronous host calls, 2 = always
     int cond_rerun = 1;            // MSIREN_RANGE_RERUN=0 (A/B knob: what the conditional launch costs): f16x3 launches go unguarded
@@ -152,9 +154,15 @@ struct msiren_ctx {
     int cus_limit = 256;       // MSIREN_GRID: cap on the persistent grids
     int ring_force = 0;        // MSIREN_F16_RING: 3 / 4 forces the weight ring depth of the register-resident trunk
     int half_allowed = 1;      // MSIREN_F16_HALF=0: never use the half-unit instance
-    int host_register = 1;     // MSIREN_HOST_REGISTER=0: pageable caller buffers are never page-locked for the duration of a call (A/B knob)
+    // MSIREN_HOST_REGISTER=1: the pageable tiles of a one-chunk host call are page-locked for the call's duration (the whole pages inside them) and
+    // read in place: 30 us per slice faster -- and OFF by default: with per-call hipHostRegister / hipHostUnregister in the process the GPU suite
+    // died about one run in three with "Memory access fault by GPU ... Reason: Unknown" at a page-aligned HOST address inside a later
+    // copy of the runtime's own (hipMemcpy from a std::vector in msiren_commit_weights, twice; a pageable download, once), each time shortly
+    // after the tests that register from two threads; without it, never (profiles/r5/14_*).  Registering only pages no other buffer can share
+    // did not cure it, so the cause is below this library; what is in place by default is page-locked memory only (see HostLock).
+    int host_register = 0;
     int zc_out = 1, zc_in = 1;  // MSIREN_ZC_OUT / MSIREN_ZC_IN: kernels write / read page-locked caller buffers in place (A/B knobs)
-    int recon_zc = 5;           // MSIREN_RECON_ZC: host slice -> slice call: 1 = reconstruction stored in place, 2 = image read in place, 4 = image by DMA from locked pages
+    int recon_zc = 1;           // MSIREN_RECON_ZC: host slice -> slice call on page-locked buffers: 1 = reconstruction stored in place, 2 = image read in place
     int host_pipe_min = 2400;  // MSIREN_HOST_PIPE_MIN: tiles from which a host call cuts itself into chunks (below: one chunk, buffers in place; profiles/r5/04_*)
     int host_first = 112, host_piece = 400;  // MSIREN_HOST_FIRST / MSIREN_HOST_PIECE: tiles in the first / the further chunks of a pipelined host call
     int host_chunks = 0;       // MSIREN_HOST_CHUNKS: chunks a synchronous host call cuts itself into (0 = default)
@@ -1517,17 +1525,30 @@ void* host_pinned_dev(const void* p) {
     return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
 }
 
-// A caller's host buffer for the duration of one call.  Three ways through a call, chosen here under ONE process-wide lock:
-//   * device view: page-locked memory of the caller's own as it is; ordinary pageable memory through hipHostRegister (4-6 us for a slice's
-//     buffers), released again by the destructor.  Registrations are reference-counted: two handles in two threads that are handed the same
-//     array (or a window inside it) share one, and the first call to return does not unlock the pages under the other's kernels;
+// A caller's host buffer for the duration of one call, decided here under ONE process-wide lock:
+//   * full device view (device_view): page-locked memory of the caller's own (msiren_host_alloc, a pinned torch tensor, ...), used as it is;
+//   * interior view (interior_view; INPUT tiles only): ordinary pageable memory is page-locked for the call's duration (hipHostRegister, 4-6 us)
+//     -- but only the WHOLE PAGES INSIDE the caller's range.  On this platform a registration maps pages at their own virtual address into
+//     the GPU's address space, so two registrations that share a page (a numpy array begins 16 bytes into a page: its first page also holds
+//     the tail of its neighbour on the heap, which the runtime may have pinned for a copy of its own, or another thread's call may have
+//     registered) share ONE mapping -- and whoever unregisters first takes the page away from the other.  Round 5 registered whole ranges at
+//     first; the GPU suite then died about one run in four with "Memory access fault by GPU ... on address <page-aligned host address>"
+//     inside a later runtime copy (profiles/r5/14_*).  Pages that lie wholly inside the caller's range can hold nobody else's bytes; the
+//     first / last tile that reaches into a shared page goes through the handle's own page-locked scratch (EncoderParams::seam).
+//     Registrations are reference-counted: handles in different threads that are handed the same array (or windows inside it) share one;
 //   * runtime copies (hipMemcpyAsync on the caller's pointer): the range is entered in a list of ranges being copied, and NO registration is
 //     made over such a range while it is there -- the runtime treats a pointer inside a registration as page-locked (the registration would
 //     end under the copy) and refuses a copy whose range leaves the registration ("invalid argument": tools/soak.py found it);
 //   * bounce buffer (partial()): the range is page-locked in PART -- a neighbour's call on an overlapping window, a caller's own partial
-//     hipHostRegister -- so neither of the above is safe on it: the call copies it by CPU into / out of page-locked memory of its own.
+//     hipHostRegister -- so none of the above is safe on it: the call copies it by CPU into / out of page-locked memory of its own.
+struct HostView {
+    void* dev = nullptr;     // device address of the range's FIRST byte (nullptr: no view)
+    size_t lo = 0, hi = 0;   // bytes [lo, hi) of the range may be touched through it
+};
+
 class HostLock {
     struct Entry { size_t bytes; void* dev; int refs; };
+    static constexpr uintptr_t PAGE = 4096;
     static std::mutex& mu() { static std::mutex m; return m; }
     static std::map<uintptr_t, Entry>& table() { static std::map<uintptr_t, Entry> t; return t; }
     static std::vector<std::pair<uintptr_t, size_t>>& copies() { static std::vector<std::pair<uintptr_t, size_t>> c; return c; }
@@ -1536,7 +1557,35 @@ class HostLock {
     size_t copy_n_ = 0;   // the range this object has entered in copies() (0: none)
     bool partial_ = false;
 
+    // 0: no registration of ours touches [a, a + bytes); 1: one contains it (`it`); 2: one covers part of it
+    static int ours(uintptr_t a, size_t bytes, std::map<uintptr_t, Entry>::iterator& hit) {
+        auto it = table().upper_bound(a);
+        if (it != table().end() && it->first < a + bytes) return 2;
+        if (it != table().begin()) {
+            --it;
+            if (a >= it->first && a + bytes <= it->first + it->second.bytes) { hit = it; return 1; }
+            if (it->first + it->second.bytes > a) return 2;
+        }
+        return 0;
+    }
+    // the caller's own page-locked memory: 1 = all of the range (dev set), 2 = part of it, 0 = none
+    static int foreign(const void* host, size_t bytes, void*& dev) {
+        void* const d_last = bytes > 1 ? host_pinned_dev((const char*)host + bytes - 1) : nullptr;
+        if (void* d = host_pinned_dev(host)) {
+            if (bytes <= 1 || d_last == (char*)d + bytes - 1) { dev = d; return 1; }
+            return 2;
+        }
+        return d_last ? 2 : 0;
+    }
+    void enter_copy(uintptr_t a, size_t bytes) {
+        copies().emplace_back(a, bytes);
+        copy_a_ = a;
+        copy_n_ = bytes;
+    }
+
 public:
+    // the range is page-locked in PART (by a neighbour's call, or by the caller): neither a device view nor a runtime copy is safe on it --
+    // hipMemcpy refuses a range that begins inside a registration and ends outside it -- so the call goes through a bounce buffer
     bool partial() const { return partial_; }
     HostLock() = default;
     HostLock(const HostLock&) = delete;
@@ -1561,48 +1610,66 @@ public:
                 }
         }
     }
-    // device address of the range, or nullptr: then partial() says whether the caller may copy from / to it through the runtime or must bounce
-    void* device_view(const void* host, size_t bytes, bool may_register) {
+    // Device address of the WHOLE range -- the caller's own page-locked memory, or a range inside a registration of ours -- or nullptr: then
+    // partial() says whether the caller may copy from / to it through the runtime (the range is entered in copies()) or must bounce.  Never registers.
+    void* device_view(const void* host, size_t bytes) {
         const uintptr_t a = (uintptr_t)host;
+        std::lock_guard<std::mutex> g(mu());
+        std::map<uintptr_t, Entry>::iterator it;
+        const int o = ours(a, bytes, it);
+        if (o == 1) {
+            it->second.refs++;
+            base_ = it->first;
+            return (char*)it->second.dev + (a - it->first);
+        }
+        if (o == 2) { partial_ = true; return nullptr; }
+        void* d = nullptr;
+        const int f = foreign(host, bytes, d);
+        if (f == 1) return d;
+        if (f == 2) { partial_ = true; return nullptr; }
+        enter_copy(a, bytes);
+        return nullptr;
+    }
+    // As device_view, but pageable memory is page-locked for the call: the whole pages inside the range, if they are at least `min_bytes`.
+    HostView interior_view(const void* host, size_t bytes, size_t min_bytes) {
+        const uintptr_t a = (uintptr_t)host;
+        const uintptr_t lo = (a + PAGE - 1) / PAGE * PAGE, hi = (a + bytes) / PAGE * PAGE;
         std::lock_guard<std::mutex> g(mu());  // (one critical section: of two threads that come with the same new buffer, the second finds the first's entry)
-        auto it = table().upper_bound(a);
-        if (it != table().end() && it->first < a + bytes) { partial_ = true; return nullptr; }  // a registration of ours begins inside the range
-        if (it != table().begin()) {
-            --it;
-            if (a >= it->first && a + bytes <= it->first + it->second.bytes) {  // one that contains the range: share it
-                it->second.refs++;
-                base_ = it->first;
-                return (char*)it->second.dev + (a - it->first);
-            }
-            if (it->first + it->second.bytes > a) { partial_ = true; return nullptr; }  // one that covers its front
+        std::map<uintptr_t, Entry>::iterator it;
+        int o = ours(a, bytes, it);
+        if (o == 1) {
+            it->second.refs++;
+            base_ = it->first;
+            return {(char*)it->second.dev + (a - it->first), 0, bytes};
         }
-        void* const d_last = bytes > 1 ? host_pinned_dev((const char*)host + bytes - 1) : nullptr;
-        if (void* d = host_pinned_dev(host)) {  // the caller's own page-locked memory -- all of the range, not just its first byte
-            if (bytes <= 1 || d_last == (char*)d + bytes - 1) return d;
-            partial_ = true;
-            return nullptr;
+        if (o == 2 && hi > lo && ours(lo, hi - lo, it) == 1) {  // (the same array once more: its inside pages are registered already)
+            it->second.refs++;
+            base_ = it->first;
+            return {(char*)it->second.dev - (it->first - a), (size_t)(lo - a), (size_t)(hi - a)};  // (lo >= it->first: the view's first valid byte is lo)
         }
-        if (d_last) { partial_ = true; return nullptr; }
+        if (o == 2) { partial_ = true; return {}; }
+        void* d = nullptr;
+        const int f = foreign(host, bytes, d);
+        if (f == 1) return {d, 0, bytes};
+        if (f == 2) { partial_ = true; return {}; }
         bool being_copied = false;
         for (const auto& c : copies()) being_copied = being_copied || (c.first < a + bytes && a < c.first + c.second);
-        if (may_register && !being_copied) {
-            if (hipHostRegister((void*)host, bytes, hipHostRegisterDefault) == hipSuccess) {
-                void* d = nullptr;
-                if (hipHostGetDevicePointer(&d, (void*)host, 0) == hipSuccess && d) {
-                    table()[a] = Entry{bytes, d, 1};
-                    base_ = a;
-                    return d;
+        if (!being_copied && hi > lo && hi - lo >= min_bytes) {
+            if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
+                void* dl = nullptr;
+                if (hipHostGetDevicePointer(&dl, (void*)lo, 0) == hipSuccess && dl) {
+                    table()[lo] = Entry{(size_t)(hi - lo), dl, 1};
+                    base_ = lo;
+                    return {(char*)dl - (lo - a), (size_t)(lo - a), (size_t)(hi - a)};
                 }
                 (void)hipGetLastError();
-                (void)hipHostUnregister((void*)host);
+                (void)hipHostUnregister((void*)lo);
             } else {
                 (void)hipGetLastError();
             }
         }
-        copies().emplace_back(a, bytes);
-        copy_a_ = a;
-        copy_n_ = bytes;
-        return nullptr;
+        enter_copy(a, bytes);
+        return {};
     }
 };
 
@@ -1633,7 +1700,7 @@ class HostSrc {
 public:
     HostSrc(const void* host, size_t n) : p_(host) {
         if (!host || !n) return;
-        (void)lock_.device_view(host, n, false);
+        (void)lock_.device_view(host, n);
         if (!lock_.partial()) return;
         if (b_.alloc(n)) { std::memcpy(b_.p, host, n); p_ = b_.p; } else ok_ = false;
     }
@@ -1651,7 +1718,7 @@ class HostDst {
 public:
     HostDst(void* host, size_t n) : user_(host), p_(host), n_(n) {
         if (!host || !n) return;
-        (void)lock_.device_view(host, n, false);
+        (void)lock_.device_view(host, n);
         if (!lock_.partial()) return;
         if (b_.alloc(n)) p_ = b_.p; else ok_ = false;
     }
@@ -1861,7 +1928,7 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     if (const char* e = std::getenv("MSIREN_HOST_REGISTER")) h->host_register = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_ZC_OUT")) h->zc_out = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_ZC_IN")) h->zc_in = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_RECON_ZC")) h->recon_zc = std::atoi(e) & 7;
+    if (const char* e = std::getenv("MSIREN_RECON_ZC")) h->recon_zc = std::atoi(e) & 3;
     if (const char* e = std::getenv("MSIREN_HOST_PIPE_MIN")) h->host_pipe_min = std::max(128, std::atoi(e));
     if (const char* e = std::getenv("MSIREN_HOST_FIRST")) h->host_first = std::max(16, std::atoi(e));
     if (const char* e = std::getenv("MSIREN_HOST_PIECE")) h->host_piece = std::max(64, std::atoi(e));
@@ -1894,6 +1961,8 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
         e = hipHostGetDevicePointer((void**)&h->status_dev, (void*)h->status_host, 0);
     }
 
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->seam_host, 2 * 32 * 32 * sizeof(float), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->seam_dev, (void*)h->seam_host, 0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -1911,6 +1980,7 @@ int msiren_destroy(msiren_handle h) {
         if (c.s) (void)hipStreamSynchronize(c.s);
     if (h->comm) (void)msiren_comm_destroy(h);
     if (h->status_host) (void)hipHostFree((void*)h->status_host);
+    if (h->seam_host) (void)hipHostFree((void*)h->seam_host);
     if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
     if (h->d_wp16n) (void)hipFree(h->d_wp16n);
     if (h->d_emw) (void)hipFree(h->d_emw);
@@ -2167,19 +2237,20 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     }
     const int nchunks = (int)plan.size();
     const size_t tile_elems = (size_t)h->O * h->O;
-    // Page-locked buffers (round 5): the trunk stores its 0.9 MB per slice straight into the caller's output array over the course of its
-    // 265 us -- no download, no wait for one behind the stream -- and the conv kernel reads the caller's tiles in place.
+    // In place (round 5): where the caller's OUTPUT array is page-locked memory (msiren_host_alloc; the Python mirror's outputs come from a
+    // recycling pool of such blocks by default; a pinned torch tensor) the trunk stores its 0.9 MB per slice straight into it over the course
+    // of its 265 us -- no download, no wait for one behind the stream.  The caller's TILES are read in place by the conv kernel: page-locked
+    // memory as it is, pageable memory (a numpy array) through a registration of the whole pages inside it for the call's duration, the
+    // first / last tile that reaches into a page shared with a neighbour through the handle's own scratch (HostLock, EncoderParams::seam).
     // One-chunk calls only: same box, 400 tiles: 390 us with both copies, 369 with the output in place, 360 with the tiles in place as well;
     // a cut call of 3 200 tiles: 2.24 ms with copies (they run beside the other chunk's kernels anyway), 2.35-2.87 ms in place
     // (tools/host_zero_copy_ab.py, profiles/r5/04_host_call_pipelining.txt).
-    // Pageable buffers of a one-chunk call of >= 64 tiles are page-locked for the duration of the call (hipHostRegister: 4-6 us for a slice's
-    // 1.6 + 0.9 MB on this system, tools/host_register_cost.py) and then treated alike: numpy -> numpy 419 -> 358 us.  If the runtime refuses
-    // (a range that overlaps a registered one, no memory to lock) the call copies as before.  (HostLock: process-wide, reference-counted.)
     HostLock reg_out, reg_in;  // (released when the call returns: behind sync_all)
-    const bool may_lock = h->host_register && B >= 64 && nchunks == 1 && h->zc_out;
     // (cut calls ask too: a buffer inside a neighbour's registration keeps that registration alive under this call's copies)
-    void* view_out = reg_out.device_view(out_host, no, may_lock);
-    void* view_in = reg_in.device_view(tiles_host, nt, may_lock && view_out && h->zc_in);
+    void* view_out = reg_out.device_view(out_host, no);
+    const bool may_lock = h->host_register && h->zc_in && B >= 64 && nchunks == 1 && h->em_enc && use_f16x3(h);
+    HostView vin = may_lock ? reg_in.interior_view(tiles_host, nt, 64 * 1024) : HostView{reg_in.device_view(tiles_host, nt), 0, nt};
+    if (!vin.dev) vin = HostView{};
     // A buffer that is page-locked in part (another thread's call on an overlapping window of the same array; a caller's own partial
     // hipHostRegister) goes through a page-locked bounce buffer of this call's own: rare, slow (an allocation and a CPU copy), correct.
     HostBounce bounce_out, bounce_in;
@@ -2193,10 +2264,25 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
         if (!bounce_in.alloc(nt)) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer of %zu bytes", nt);
         std::memcpy(bounce_in.p, tiles_host, nt);
         tiles_host = (const float*)bounce_in.p;
-        view_in = host_pinned_dev(tiles_host);
+        vin = HostView{host_pinned_dev(tiles_host), 0, nt};
     }
     float* out_zc_ = h->zc_out && nchunks == 1 ? (float*)view_out : nullptr;
-    const float* in_zc_ = h->zc_in && nchunks == 1 && out_zc_ ? (const float*)view_in : nullptr;
+    const float* in_zc_ = h->zc_in && nchunks == 1 ? (const float*)vin.dev : nullptr;
+    // the tiles that are not wholly inside the view's valid bytes: at most the first and the last one (a tile is as large as a page)
+    const size_t tile_bytes = tile_elems * sizeof(float);
+    const int64_t head = in_zc_ ? (int64_t)((vin.lo + tile_bytes - 1) / tile_bytes) : 0, tail_from = in_zc_ ? (int64_t)(vin.hi / tile_bytes) : B;
+    if (in_zc_ && (head > 1 || B - tail_from > 1 || tail_from <= head || !h->seam_host)) in_zc_ = nullptr;  // (not this shape: copies)
+    if (in_zc_ && (head || tail_from < B)) {
+        if (head) std::memcpy(h->seam_host, tiles_host, tile_bytes);
+        if (tail_from < B) std::memcpy(h->seam_host + tile_elems, tiles_host + (size_t)tail_from * tile_elems, tile_bytes);
+        h->enc.seam = h->seam_dev;
+        h->enc.seam_head = (int)head;
+        h->enc.seam_tail = (int)tail_from;
+    }
+    struct SeamOff {  // (the handle's encoder parameters go back to "every tile where the pointer says")
+        msiren_ctx* h;
+        ~SeamOff() { h->enc.seam = nullptr; h->enc.seam_head = 0; h->enc.seam_tail = 0x7fffffff; }
+    } seam_off{h};
     float* const out_zc = out_zc_;
     const float* const in_zc = in_zc_;
     float* const out_base = out_zc ? out_zc : (float*)h->ws_out.p;
@@ -2461,16 +2547,16 @@ static int msiren_reconstruct_slices_impl(msiren_handle h, const float* images_h
     const size_t ni = (size_t)n * height * width * sizeof(float);
     const size_t nr = (size_t)n * nV * h->I * nH * h->I * sizeof(float);
     if ((rc = ensure(h, h->ws_in, ni)) || (rc = ensure(h, h->ws_img, nr))) return rc;
-    // Round 5, as in msiren_forward_tiles: the caller's buffers are page-locked for the call's duration (HostLock); the fold stores the
-    // reconstruction straight into the caller's array (recon_zc & 1), the image is fetched by an asynchronous DMA copy from the locked pages
-    // (& 4) or read in place by image_to_patches (& 2: every pixel crosses the link four times -- 32 x 32 tiles at a stride of 16).
-    // tools/host_reconstruct_ab.py.  A buffer that is page-locked in part goes through a bounce buffer.
+    // Round 5, as in msiren_forward_tiles: where the caller's reconstruction array is page-locked memory (the Python mirror's outputs are, by
+    // default) the fold stores straight into it (recon_zc & 1); a page-locked image is read in place by image_to_patches (& 2: every pixel
+    // crosses the link four times -- 32 x 32 tiles at a stride of 16 -- so off by default) or fetched by an asynchronous DMA copy.
+    // Pageable buffers are copied by the runtime: nothing of the caller's is registered here (HostLock: why).  tools/host_reconstruct_ab.py.
     auto& sc = h->sc[h->cur];
-    const int zc = h->host_register ? h->recon_zc : 0;
+    const int zc = h->recon_zc;
     HostLock reg_out, reg_in;
     HostBounce bounce_out, bounce_in;
-    void* view_out = reg_out.device_view(recon_host, nr, (zc & 1) != 0);
-    void* view_in = reg_in.device_view(images_host, ni, (zc & 6) != 0);
+    void* view_out = reg_out.device_view(recon_host, nr);
+    void* view_in = reg_in.device_view(images_host, ni);
     float* const recon_user = recon_host;
     if (reg_out.partial()) {
         if (!bounce_out.alloc(nr)) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer of %zu bytes", nr);

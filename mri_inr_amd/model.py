@@ -97,24 +97,33 @@ class _PinnedBlock:
 
 class _PinnedPool:
     """Recycles page-locked blocks by size (hipHostMalloc costs ~100 us; the blocks of a steady loop are reused).  At most
-    `keep` idle blocks per size are kept; the rest is freed."""
+    `keep` idle blocks per size are kept; the rest is freed.  `cap_bytes` bounds what is handed out at one time when the caller
+    did not ask for page-locked memory explicitly (the default outputs of the host-pointer calls): beyond it array() returns
+    None and the caller falls back to ordinary memory -- an application that keeps thousands of outputs alive does not pin them all."""
 
-    def __init__(self, model, keep=8):
-        self._model, self._free, self._keep = model, {}, keep
+    def __init__(self, model, keep=8, cap_bytes=512 << 20):
+        self._model, self._free, self._keep, self._cap, self._out = model, {}, keep, cap_bytes, 0
 
-    def array(self, shape) -> np.ndarray:
+    def array(self, shape, strict=True):
         shape = tuple(int(x) for x in shape)
         nbytes = max(4, int(np.prod(shape, dtype=np.int64)) * 4)
+        if not strict and self._out + nbytes > self._cap:
+            return None
         lst = self._free.get(nbytes)
         if lst:
             ptr = lst.pop()
         else:
             p = C.c_void_p()
-            _lib.check(self._model._lib.msiren_host_alloc(self._model._h, nbytes, C.byref(p)))
+            rc = self._model._lib.msiren_host_alloc(self._model._h, nbytes, C.byref(p))
+            if rc != 0 and not strict:
+                return None
+            _lib.check(rc)
             ptr = p.value
+        self._out += nbytes
         return np.asarray(_PinnedBlock(self, ptr, nbytes, shape))
 
     def _give_back(self, ptr, nbytes):
+        self._out -= nbytes
         lst = self._free.setdefault(nbytes, [])
         if len(lst) < self._keep and self._model._h:
             lst.append(ptr)
@@ -165,7 +174,7 @@ class ModulatedSiren:
         self._lib = None
         self._h = None
         self._pinned = _PinnedPool(self)   # page-locked host arrays (pinned_empty, pin_outputs)
-        self._pin_outputs = False
+        self._pin_outputs = True           # outputs of the host-pointer calls come from the pool (the kernels store into them in place)
         self._device = _device_index(device)
         self._committed = False
         # a fresh model has random weights, like a fresh nn.Module
@@ -407,7 +416,9 @@ class ModulatedSiren:
         a = np.ascontiguousarray(x, dtype=np.float32)
         self._check_tail(a.shape, in_tail)
         B = out_shape_fn(a.shape)
-        out = self._pinned.array((B, S, S)) if self._pin_outputs and B else np.empty((B, S, S), dtype=np.float32)
+        out = self._pinned.array((B, S, S), strict=False) if self._pin_outputs and B else None
+        if out is None:
+            out = np.empty((B, S, S), dtype=np.float32)
         args = [self._h, a.ctypes.data if a.size else None, B, out.ctypes.data if out.size else None] + [None] * extra_null
         _lib.check(host_fn(*args))
         return out
@@ -507,7 +518,9 @@ class ModulatedSiren:
         nv, nh = C.c_int32(), C.c_int32()
         _lib.check(self._lib.msiren_recon_shape(self._h, Hh, Ww, C.byref(nv), C.byref(nh)))
         I = self.inner_patch_size
-        out = np.empty((n, nv.value * I, nh.value * I), dtype=np.float32)
+        out = self._pinned.array((n, nv.value * I, nh.value * I), strict=False) if self._pin_outputs and n else None
+        if out is None:
+            out = np.empty((n, nv.value * I, nh.value * I), dtype=np.float32)
         _lib.check(self._lib.msiren_reconstruct_slices(self._h, a.ctypes.data, n, Hh, Ww, out.ctypes.data))
         res = out[0] if single else out
         if _is_torch(images):
@@ -525,8 +538,9 @@ class ModulatedSiren:
         return self._pinned.array(shape)
 
     def pin_outputs(self, on: bool = True):
-        """Return the host-pointer calls' outputs in page-locked arrays from a recycling pool (off by default: pinned memory is a
-        finite resource, and an application that keeps thousands of outputs alive should not pin them)."""
+        """Outputs of the host-pointer calls in page-locked arrays from a recycling pool -- the kernels store into them in place, no
+        download.  On by default since round 5, bounded: at most 512 MB of such outputs alive at a time (beyond that, ordinary arrays).
+        pin_outputs(False): ordinary numpy arrays always."""
         self._ensure_handle()
         self._pin_outputs = bool(on)
         return self
