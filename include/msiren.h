@@ -18,9 +18,9 @@
  *     msiren_timer_stop()) before reading results;
  *   - one handle = one device + one stream + one weight set; handles are independent and may be
  *     used from different threads (a single handle is not re-entrant);
- *   - threads may hand their handles the same host arrays, or windows of one array that touch or overlap: inputs are only read, and
- *     the library keeps its per-call page-locking out of the way of a neighbour's call (a window that is page-locked only in part is
- *     copied through a bounce buffer).  Two calls that WRITE overlapping output ranges race, as any two writers do.
+ *   - threads may hand their handles the same host arrays, or windows of one array that touch or overlap: inputs are only read (a
+ *     window that is page-locked only in part is copied through a bounce buffer).  Two calls that WRITE overlapping output ranges
+ *     race, as any two writers do.
  */
 #ifndef MSIREN_H
 #define MSIREN_H
@@ -176,8 +176,7 @@ MSIREN_API int msiren_forward_tiles_dev(msiren_handle h, const float* tiles_dev,
  * tiling.py:184-198,244-271) -> ModulatedSiren.forward on the non-black tiles -> zeros re-inserted
  * (tiling.py:274-303) -> weighted overlap-add (tiling.py:67-140) -> recon (nV*I, nH*I).
  * n_slices images of identical size are processed as one batch.  recon_rows/cols may be NULL.
- * The host-pointer form page-locks the caller's two buffers for the call (as msiren_forward_tiles does, see msiren_host_alloc below): the
- * fold stores into recon_host itself, the image arrives by DMA from the locked pages. */
+ * The host-pointer form stores the reconstruction straight into recon_host where that is page-locked memory (see msiren_host_alloc below). */
 MSIREN_API int msiren_reconstruct_slices_dev(msiren_handle h, const float* images_dev, int64_t n_slices, int32_t height,
                                   int32_t width, float* recon_dev);
 MSIREN_API int msiren_reconstruct_slices(msiren_handle h, const float* images_host, int64_t n_slices, int32_t height,
@@ -263,13 +262,16 @@ MSIREN_API int msiren_comm_destroy(msiren_handle h);
 
 MSIREN_API int msiren_dev_alloc(msiren_handle h, size_t bytes, void** dev_ptr);
 MSIREN_API int msiren_dev_free(msiren_handle h, void* dev_ptr);
-/* Host buffers of the host-pointer entry points (round 5).  msiren_forward_tiles of fewer than 2400 tiles runs as ONE chunk whose kernels
- * read the caller's tiles and store into the caller's output array IN PLACE: page-locked memory -- from here, or any memory the HIP runtime
- * has page-locked: a torch tensor after .pin_memory(), what the reference's DataLoader delivers with pin_memory=True -- as it is; ordinary
- * pageable memory (a numpy array) is page-locked by the library for the duration of the call (hipHostRegister, a few microseconds;
- * process-wide and reference-counted, so threads may share an input array) -- one 320x320 slice numpy -> numpy: 437 -> 359 us.  Larger
- * calls cut themselves into chunks over the handle's two streams, with copies that run beside the other chunk's kernels.
- * Same results either way, bit for bit. */
+/* Host buffers of the host-pointer entry points (round 5).  Where a caller's buffer is page-locked memory -- from here, or any memory the HIP
+ * runtime has page-locked: a torch tensor after .pin_memory(), what the reference's DataLoader delivers with pin_memory=True -- the kernels of
+ * a msiren_forward_tiles call of fewer than 2400 tiles work on it IN PLACE (the trunk stores into the output array, the conv kernel reads the
+ * tiles), and msiren_reconstruct_slices stores the reconstruction into it; ordinary pageable memory is copied by the runtime.  The Python
+ * mirror takes its OUTPUT arrays from a bounded recycling pool of these blocks by default: one 320x320 slice numpy -> numpy 485 (round 4) ->
+ * 380 us, 364 with page-locked tiles as well.  Larger calls cut themselves into chunks over the handle's two streams, with copies that run
+ * beside the other chunk's kernels.  Same results either way, bit for bit.
+ * (Page-locking the caller's pageable buffers for the duration of a call -- hipHostRegister, ~5 us, 359 us per slice -- shipped for a few
+ * hours and is off: with it the GPU test suite died about one run in three inside the runtime's own copies; MSIREN_HOST_REGISTER=1,
+ * profiles/r5/14_*.) */
 MSIREN_API int msiren_host_alloc(msiren_handle h, size_t bytes, void** host_ptr);
 MSIREN_API int msiren_host_free(msiren_handle h, void* host_ptr);
 MSIREN_API int msiren_memcpy_h2d(msiren_handle h, void* dst_dev, const void* src_host, size_t bytes);
