@@ -179,8 +179,8 @@ def test_committed_bench_line_follows_the_contract():
     assert abs(r5["frac"] - r5["achieved"] / r5["peak"]) < 1e-9 and "profiles/r5/" in r5["traffic_source"] and 1e7 < r5["traffic"] < 3e7
     assert l5["roofline_kernel_alone"]["kernel"] == "siren_trunk_f16x3w_kernel<0,4>" and l5["cpu_baseline"]["kind"] == "port"
     e5 = l5["extra"]
-    # pageable arrays are page-locked for the call and used in place like page-locked ones: the two rates agree, both above round 4's target
-    assert 270 < e5["host_to_host_mpixel_s"] < l5["value"] and abs(e5["host_to_host_pinned_mpixel_s"] / e5["host_to_host_mpixel_s"] - 1) < 0.03
+    # outputs come from the page-locked pool (stored in place), pageable tiles are copied: between round 4's 211 and the page-locked rate
+    assert 250 < e5["host_to_host_mpixel_s"] <= e5["host_to_host_pinned_mpixel_s"] * 1.02 < l5["value"] and e5["host_slice_to_slice_mpixel_s"] > 0
     assert e5["host_to_host_8_slices_mpixel_s"] > e5["host_to_host_mpixel_s"]
     for name in ("config3_64_slices_n1", "config3_64_slices_n1_one_stream", "config3_8_slices_per_rank", "config4_morlet", "fp32_trunk",
                  "config5_deep_residual_bf16"):
