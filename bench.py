@@ -648,9 +648,7 @@ def extras(model, lib, h, _lib, d_img, d_tiles, d_recons, streams, budget_s=0.5)
     # slices, which cuts itself into chunks over the handle's two streams (uploads and downloads beside the other chunk's kernels)
     pin = model.pinned_empty(tiles.shape)
     pin[...] = tiles
-    model.pin_outputs(True)
-    h2h_pinned = host_rate(pin, 1)
-    model.pin_outputs(False)
+    h2h_pinned = host_rate(pin, 1)   # (outputs come from the page-locked pool by default: here the tiles are page-locked as well)
     eight = np.concatenate([tiles] * 8)
     h2h_8 = host_rate(eight, 8)
     del pin, eight
@@ -682,7 +680,7 @@ def extras(model, lib, h, _lib, d_img, d_tiles, d_recons, streams, budget_s=0.5)
     return {"host_to_host_mpixel_s": h2h, "host_to_host_pinned_mpixel_s": h2h_pinned, "host_to_host_8_slices_mpixel_s": h2h_8,
             "reconstruct_mpixel_s": rec, "host_slice_to_slice_mpixel_s": h2h_rec,
             "note": "after the timed region: host numpy -> host numpy through msiren_forward_tiles (PCIe-inclusive), one 320x320 slice per call "
-                    "on pageable arrays, on page-locked ones (model.pinned_empty / pin_outputs), 8 slices per call on pageable arrays (the call "
+                    "on pageable tiles (outputs from the mirror's page-locked pool, its default), on page-locked tiles as well (model.pinned_empty), 8 slices per call on pageable tiles (the call "
                     "pipelines itself); the device-resident slice -> slice pipeline, one slice per call; and the same pipeline as one synchronous call "
                     "per slice on host arrays (msiren_reconstruct_slices: host_slice_to_slice)"}
 
