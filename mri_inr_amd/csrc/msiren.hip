@@ -1633,7 +1633,8 @@ public:
     // As device_view, but pageable memory is page-locked for the call: the whole pages inside the range, if they are at least `min_bytes`.
     HostView interior_view(const void* host, size_t bytes, size_t min_bytes) {
         const uintptr_t a = (uintptr_t)host;
-        const uintptr_t lo = (a + PAGE - 1) / PAGE * PAGE, hi = (a + bytes) / PAGE * PAGE;
+        const msiren::InsidePages in = msiren::inside_pages(a, bytes, PAGE);  // (host_plan.h: unit-tested on the CPU)
+        const uintptr_t lo = in.lo, hi = in.hi;
         std::lock_guard<std::mutex> g(mu());  // (one critical section: of two threads that come with the same new buffer, the second finds the first's entry)
         std::map<uintptr_t, Entry>::iterator it;
         int o = ours(a, bytes, it);
@@ -2270,8 +2271,9 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     const float* in_zc_ = h->zc_in && nchunks == 1 ? (const float*)vin.dev : nullptr;
     // the tiles that are not wholly inside the view's valid bytes: at most the first and the last one (a tile is as large as a page)
     const size_t tile_bytes = tile_elems * sizeof(float);
-    const int64_t head = in_zc_ ? (int64_t)((vin.lo + tile_bytes - 1) / tile_bytes) : 0, tail_from = in_zc_ ? (int64_t)(vin.hi / tile_bytes) : B;
-    if (in_zc_ && (head > 1 || B - tail_from > 1 || tail_from <= head || !h->seam_host)) in_zc_ = nullptr;  // (not this shape: copies)
+    const msiren::SeamTiles st = msiren::seam_tiles(vin.lo, vin.hi, tile_bytes, B);  // (host_plan.h)
+    const int64_t head = in_zc_ ? st.head : 0, tail_from = in_zc_ ? st.tail_from : B;
+    if (in_zc_ && (!st.ok || !h->seam_host)) in_zc_ = nullptr;  // (not this shape: copies)
     if (in_zc_ && (head || tail_from < B)) {
         if (head) std::memcpy(h->seam_host, tiles_host, tile_bytes);
         if (tail_from < B) std::memcpy(h->seam_host + tile_elems, tiles_host + (size_t)tail_from * tile_elems, tile_bytes);
