@@ -273,7 +273,7 @@ MSIREN_API int msiren_dev_free(msiren_handle h, void* dev_ptr);
  * hours and is off: with it the GPU test suite died about one run in three inside the runtime's own copies; MSIREN_HOST_REGISTER=1,
  * profiles/r5/14_*.) */
 MSIREN_API int msiren_host_alloc(msiren_handle h, size_t bytes, void** host_ptr);
-MSIREN_API int msiren_host_free(msiren_handle h, void* host_ptr);
+MSIREN_API int msiren_host_free(msiren_handle h, void* host_ptr);   /* h may be NULL: a block that has outlived its handle */
 MSIREN_API int msiren_memcpy_h2d(msiren_handle h, void* dst_dev, const void* src_host, size_t bytes);
 MSIREN_API int msiren_memcpy_d2h(msiren_handle h, void* dst_host, const void* src_dev, size_t bytes);
 

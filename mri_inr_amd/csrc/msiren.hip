@@ -2634,6 +2634,10 @@ int msiren_host_alloc(msiren_handle h, size_t bytes, void** host_ptr) {
 }
 
 int msiren_host_free(msiren_handle h, void* host_ptr) {
+    if (!h) {  // a block that has outlived its handle (msiren_destroy waited for the handle's streams: nothing of it is in flight)
+        if (host_ptr) HIPCHK(hipHostFree(host_ptr));
+        return 0;
+    }
     int rc = check(h, false);
     if (rc) return rc;
     if (host_ptr) {

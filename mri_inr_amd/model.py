@@ -127,7 +127,7 @@ class _PinnedPool:
         lst = self._free.setdefault(nbytes, [])
         if len(lst) < self._keep and self._model._h:
             lst.append(ptr)
-        elif self._model._h:
+        elif self._model._lib is not None:   # (also for a block whose array has outlived the handle: freed without one)
             self._model._lib.msiren_host_free(self._model._h, ptr)
 
     def drain(self):
