@@ -18,9 +18,10 @@
  *     msiren_timer_stop()) before reading results;
  *   - one handle = one device + one stream + one weight set; handles are independent and may be
  *     used from different threads (a single handle is not re-entrant);
- *   - threads may hand their handles the same host arrays, or windows of one array that touch or overlap: inputs are only read (a
- *     window that is page-locked only in part is copied through a bounce buffer).  Two calls that WRITE overlapping output ranges
- *     race, as any two writers do.
+ *   - threads may hand their handles the same host arrays, or windows of one array that touch or overlap: inputs are only read, and
+ *     the library never page-locks, registers or otherwise changes the state of a caller's memory (a range that the CALLER has
+ *     page-locked only in part is copied through a bounce buffer: msiren_host_range_kind).  Two calls that WRITE overlapping output
+ *     ranges race, as any two writers do.
  */
 #ifndef MSIREN_H
 #define MSIREN_H
@@ -32,9 +33,11 @@
 extern "C" {
 #endif
 
-/* 2 (round 5): msiren_chain_* gone and msiren_profile_read_kernel / msiren_last_trunk_kernel / msiren_device_pci added in round 4 while the number
- * stayed 1; sync no longer returns MSIREN_E_RANGE.  A library of another number refuses msiren_create. */
-#define MSIREN_ABI_VERSION 2
+/* 3 (round 6): msiren_runtime_info, msiren_host_range_kind added; the large-call split (MSIREN_SPLIT_MIN) and the per-call page-locking of
+ * caller buffers (MSIREN_HOST_REGISTER) left the library.  2 (round 5): msiren_chain_* gone, msiren_profile_read_kernel /
+ * msiren_last_trunk_kernel / msiren_device_pci added; sync no longer returns MSIREN_E_RANGE.  A library of another number refuses
+ * msiren_create. */
+#define MSIREN_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define MSIREN_API __attribute__((visibility("default")))
@@ -217,12 +220,7 @@ MSIREN_API int msiren_scatter_rows_dev(msiren_handle h, const float* src_dev, co
  * call's kernels).  n = 3 (round 5): a rotation over three -- call k+2's encoder / Modulator no longer queue behind call k's
  * trunk, which pays where the trunk OWNS its CUs (config 5: +3.7 %; the default model: +0.1 %).  The caller then must not hand the
  * same output buffer to n consecutive calls, nor feed one call's output to the next, without an msiren_sync() in between.
- *
- * With n = 1, ONE large msiren_forward_tiles_dev call (>= MSIREN_SPLIT_MIN tiles of a depth-5 split-fp16 model; environment
- * variable read at msiren_create, default 0 = never -- behind round 5's one-launch prologue the cut no longer pays) overlaps with itself: the encoder + Modulator of most of its batch
- * (`self.modulator(self.encoder(tiles))`, modulated_siren.py:446) run on the handle's other stream beside the trunk of
- * the first 12 % of the batch, and the trunk of the rest follows on the call's stream.  Results are bit-identical to the
- * uncut call (patches are independent); the call is complete when its stream is. */
+ */
 MSIREN_API int msiren_set_streams(msiren_handle h, int32_t n);
 
 /* Blocks until everything enqueued on the handle's streams has finished (the reference's implicit
@@ -262,18 +260,21 @@ MSIREN_API int msiren_comm_destroy(msiren_handle h);
 
 MSIREN_API int msiren_dev_alloc(msiren_handle h, size_t bytes, void** dev_ptr);
 MSIREN_API int msiren_dev_free(msiren_handle h, void* dev_ptr);
-/* Host buffers of the host-pointer entry points (round 5).  Where a caller's buffer is page-locked memory -- from here, or any memory the HIP
+/* Host buffers of the host-pointer entry points.  Where a caller's buffer is page-locked memory -- from here, or any memory the HIP
  * runtime has page-locked: a torch tensor after .pin_memory(), what the reference's DataLoader delivers with pin_memory=True -- the kernels of
  * a msiren_forward_tiles call of fewer than 2400 tiles work on it IN PLACE (the trunk stores into the output array, the conv kernel reads the
  * tiles), and msiren_reconstruct_slices stores the reconstruction into it; ordinary pageable memory is copied by the runtime.  The Python
  * mirror takes its OUTPUT arrays from a bounded recycling pool of these blocks by default: one 320x320 slice numpy -> numpy 485 (round 4) ->
  * 380 us, 364 with page-locked tiles as well.  Larger calls cut themselves into chunks over the handle's two streams, with copies that run
  * beside the other chunk's kernels.  Same results either way, bit for bit.
- * (Page-locking the caller's pageable buffers for the duration of a call -- hipHostRegister, ~5 us, 359 us per slice -- shipped for a few
- * hours and is off: with it the GPU test suite died about one run in three inside the runtime's own copies; MSIREN_HOST_REGISTER=1,
- * profiles/r5/14_*.) */
+ * The library itself never calls hipHostRegister / hipHostUnregister on a caller's memory (round 5 did so per call for a few hours; the
+ * path was deleted in round 6 after an unexplained GPU memory fault in processes that used it: profiles/r6/01_*).
+ * msiren_host_range_kind: what a host range is to the entry points above -- 0 = pageable (copied by the runtime), 1 = the whole range lies
+ * inside ONE page-locked allocation (used in place), 2 = page-locked in part (it begins or ends inside a page-locked allocation that does
+ * not hold all of it: goes through a bounce buffer).  No handle: any thread, any time after the first HIP call of the process. */
 MSIREN_API int msiren_host_alloc(msiren_handle h, size_t bytes, void** host_ptr);
 MSIREN_API int msiren_host_free(msiren_handle h, void* host_ptr);   /* h may be NULL: a block that has outlived its handle */
+MSIREN_API int msiren_host_range_kind(const void* host_ptr, size_t bytes, int32_t* kind);
 MSIREN_API int msiren_memcpy_h2d(msiren_handle h, void* dst_dev, const void* src_host, size_t bytes);
 MSIREN_API int msiren_memcpy_d2h(msiren_handle h, void* dst_host, const void* src_dev, size_t bytes);
 
@@ -287,8 +288,7 @@ MSIREN_API int msiren_profile_enable(msiren_handle h, int32_t on);
 MSIREN_API int msiren_profile_read(msiren_handle h, int64_t* launches, double* trunk_ms_total);
 /* The same, per trunk instance: entry `index` (0-based, in order of first launch since msiren_profile_enable(h, 1)) ->
  * its name as launched (e.g. "siren_trunk_f16x3w_kernel<0,4>"), launch count, summed milliseconds and the coordinates
- * (patches x siren_patch_size^2) its launches evaluated -- a large call is cut in two trunk launches of different kernels
- * (below), so a roofline figure is per instance: msiren_flops_per_coord x coords_total / ms_total.  MSIREN_E_INVALID past
+ * (patches x siren_patch_size^2) its launches evaluated -- a host call of several slices runs two trunk instances, so a roofline figure is per instance: msiren_flops_per_coord x coords_total / ms_total.  MSIREN_E_INVALID past
  * the last entry.  msiren_last_trunk_kernel: the instance the most recent trunk launch of the handle used. */
 MSIREN_API int msiren_profile_read_kernel(msiren_handle h, int32_t index, char* name128, int64_t* launches, double* ms_total,
                                           int64_t* coords_total);
@@ -300,6 +300,14 @@ MSIREN_API int msiren_device_info(msiren_handle h, char* name256, int32_t* compu
 /* PCI bus id of the handle's device, "0000:c1:00.0" (<= 31 chars + NUL): which physical card a rank of a multi-GPU job sits on. */
 MSIREN_API int msiren_device_pci(msiren_handle h, char* busid32);
 MSIREN_API int msiren_device_count(int32_t* count);
+/* Which HIP runtime the library's calls are bound to IN THIS PROCESS: *runtime_version = hipRuntimeGetVersion() (e.g. 70253625),
+ * *built_against = the HIP_VERSION libmsiren.so was compiled with, *driver_version = hipDriverGetVersion(), lib_path = the file the
+ * dynamic loader mapped for libamdhip64 (dladdr of a HIP entry point).  The library links libamdhip64.so.7 by soname; a PyTorch-ROCm
+ * wheel bundles a libamdhip64.so of the same soname, so in a process that imported torch FIRST (the reference's own host program:
+ * test_mod_siren.py:1-20 imports torch before anything else) every HIP call of this library runs on torch's bundled runtime, in a
+ * torch-free process on the system one.  Any pointer may be NULL.  Needs no handle and no device. */
+MSIREN_API int msiren_runtime_info(int32_t* runtime_version, int32_t* built_against, int32_t* driver_version, char* lib_path,
+                                   size_t lib_path_bytes);
 /* Domain guard of the split-fp16 trunk (MSIREN_PREC_F16X3).  Its fp16 operands carry activation x modulation x the next
  * layer's power-of-two weight scale; the weights are scaled into range at commit, a modulation cannot be known before the
  * call.  Every f16x3 trunk launch checks the scaled modulations it stages; if one exceeds 65504 (or is not finite) it

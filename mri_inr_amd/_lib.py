@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSIREN_LIB") or os.path.join(_HERE, "libmsiren.so")  # MSIREN_LIB: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msiren.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ACT_SINE, ACT_MORLET = 0, 1
 PREC_F32, PREC_BF16, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
 E_INVALID, E_STATE, E_SHAPE, E_HIP, E_NOMEM, E_RANGE = -1, -2, -3, -4, -5, -6
@@ -90,6 +90,8 @@ PROTOTYPES = {
     "msiren_dev_free": (C.c_int, [_vp, _vp]),
     "msiren_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "msiren_host_free": (C.c_int, [_vp, _vp]),
+    "msiren_host_range_kind": (C.c_int, [_vp, C.c_size_t, C.POINTER(_i32)]),
+    "msiren_runtime_info": (C.c_int, [C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, C.c_size_t]),
     "msiren_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "msiren_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "msiren_timer_start": (C.c_int, [_vp]),
@@ -164,11 +166,15 @@ def load():
 
 
 def _init_torch_runtime_first():
-    """PyTorch-ROCm wheels bundle their own HIP/HSA runtime (soname ``libamdhip64.so``) next to the
-    system one this library links (``libamdhip64.so.7``).  Both can live in one process, but only if
-    torch's is initialised first; initialising it after ours makes ``torch.cuda`` report no GPUs.
-    So: if the host program has already imported torch, let it bring its runtime up before we dlopen
-    ours.  Nothing is imported here -- a torch-free host is unaffected."""
+    """PyTorch-ROCm wheels bundle their own HIP/HSA runtime (``torch/lib/libamdhip64.so``) under the SAME soname this
+    library links (``libamdhip64.so.7``).  A process has one of them: whichever is mapped first serves every later
+    request for that soname.  So in a host that imported torch first (the reference's own program does:
+    test_mod_siren.py imports torch at the top) libmsiren's HIP calls run on torch's bundled runtime -- ROCm 7.0 in
+    this image -- and in a torch-free host on the system one (7.2): ``runtime_info()`` / ``msiren_runtime_info`` name
+    the file that is mapped.  Both are supported and measured (profiles/r6/02_*).  The one
+    ordering that does not work is libmsiren first and torch afterwards: torch then finds the system runtime under its
+    soname and ``torch.cuda`` reports no GPUs.  Hence: if the host program has already imported torch, let it bring its
+    runtime up before we dlopen ours.  Nothing is imported here -- a torch-free host is unaffected."""
     import sys
 
     torch = sys.modules.get("torch")
@@ -179,6 +185,22 @@ def _init_torch_runtime_first():
             torch.cuda.init()
     except Exception:
         pass
+
+
+def runtime_info() -> dict:
+    """The HIP runtime libmsiren is bound to in this process (msiren_runtime_info): version, the version the library was
+    built against, the driver version, and the path of the mapped libamdhip64."""
+    lib = load()
+    rv, ba, dv = _i32(), _i32(), _i32()
+    buf = C.create_string_buffer(1024)
+    lib.msiren_runtime_info(C.byref(rv), C.byref(ba), C.byref(dv), buf, 1024)
+
+    def fmt(v):  # HIP_VERSION = major * 10^7 + minor * 10^5 + patch
+        return f"{v // 10000000}.{v // 100000 % 100}.{v % 100000}" if v else None
+
+    path = buf.value.decode()
+    return {"hip_runtime_version": fmt(rv.value), "built_against_hip": fmt(ba.value), "hip_driver_version": fmt(dv.value),
+            "libamdhip64": path, "torch_bundled": "/torch/lib/" in path}
 
 
 def last_error() -> str:

@@ -466,9 +466,7 @@ static_assert(em_tail_lds_bytes<2, 2>() <= 34 * 1024, "the H = Z = 256 instance 
 // this row's column of the row block's 64 k-step images; thread (wave w, lane) stores the 16-byte piece (k-step 16 w + (lane >> 2),
 // q = lane & 3), so conv3's k order is whatever values the thread holds (the host packs conv3's weights to match, per variant).
 //
-// VARIANT 0: conv2 on the VALU, encoder_conv_kernel's loop (fp32 FMAs in the same order: the same feature values before the
-//   split).  Thread (w, pos) holds channels 8 w + j at position pos.
-// VARIANT 1: conv2 as an implicit GEMM on the matrix cores in the split-fp16 arithmetic.  conv1 (K = 9: VALU, one thread per
+// VARIANT 1 (the only one left; the name stays what the round-5 profiles call it): conv2 as an implicit GEMM on the matrix cores in the split-fp16 arithmetic.  conv1 (K = 9: VALU, one thread per
 //   output position, all 16 channels, fp32 FMAs in the reference order) leaves its output in LDS as conv2's B operand:
 //   [padded position 17 x 17][hi: 16 channels | lo: 16 channels] x f16, scaled by the tile's own power of two.  A k-step is two
 //   taps x 16 channels (9 taps -> 5 k-steps, the tenth tap has zero weights), so a lane's eight B elements are eight consecutive
@@ -486,46 +484,8 @@ __global__ __launch_bounds__(256, 5) void encoder_conv_f16x3_kernel(EncoderParam
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     em_f4 o0, o1;  // the thread's eight features (before scale and split)
 
-    if constexpr (VARIANT == 0) {
-        constexpr int RSP = 12, PLANE = 17 * RSP;
-        __shared__ float a1[16 * 2 * PLANE];
-        for (int i = tid; i < 33 * 33; i += 256) {
-            const int y = i / 33, x = i - y * 33;
-            t0[i] = (y == 0 || x == 0) ? 0.f : tile[(y - 1) * 32 + (x - 1)];
-        }
-        for (int i = tid; i < 16 * 2 * PLANE; i += 256) a1[i] = 0.f;
-        __syncthreads();
-        for (int i = tid; i < 16 * 256; i += 256) {
-            const int c = i >> 8, y = (i >> 4) & 15, x = i & 15;
-            float s = p.c1b[c];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) s = __builtin_fmaf(t0[(2 * y + ky) * 33 + 2 * x + kx], p.c1w[c * 9 + ky * 3 + kx], s);
-            const int col = x + 1;
-            a1[(c * 2 + (col & 1)) * PLANE + (y + 1) * RSP + (col >> 1)] = leaky02(s);
-        }
-        __syncthreads();
-        const int y = lane >> 3, x = lane & 7;
-        float s[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] = p.c2b[8 * wv + j];
-        for (int c = 0; c < 16; ++c)
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const float* even = &a1[(c * 2 + 0) * PLANE + (2 * y + ky) * RSP + x];
-                const float* odd = &a1[(c * 2 + 1) * PLANE + (2 * y + ky) * RSP + x];
-                const float in[3] = {even[0], odd[0], even[1]};
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float* w = p.c2w + (c * 9 + ky * 3 + kx) * 32 + 8 * wv;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) s[j] = __builtin_fmaf(in[kx], w[j], s[j]);
-                }
-            }
-        o0 = em_f4{leaky02(s[0]), leaky02(s[1]), leaky02(s[2]), leaky02(s[3])};
-        o1 = em_f4{leaky02(s[4]), leaky02(s[5]), leaky02(s[6]), leaky02(s[7])};
-    } else {
+    static_assert(VARIANT == 1, "VARIANT 0 (conv2 on the VALU: 17.9 us against 10.3 per 400 tiles, profiles/r5/02_*) left the library in round 6");
+    {
         __shared__ __attribute__((aligned(16))) em_u4 a1img[17 * 17 * 4];  // [position][hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]
         const int n = lane & 15, q = lane >> 4, mt = wv & 1;
         // conv2's weights of this wave's channel tile: in flight while conv1 runs

@@ -18,21 +18,10 @@ struct EncoderParams {
     const void* c2f16;  // conv2 as MFMA A fragments, split fp16: [2 channel tiles][5 k-steps][hi|lo][64 lanes][8 x f16] (encoder_modulator_f16x3.hip.h)
     float c2_winv;      // exact inverse of conv2's power-of-two weight scale
     const int* plan;   // optional (compact_flags_kernel): workgroup j handles tile plan[2 + j], j < plan[0]
-    // Host-pointer calls that read the caller's tiles IN PLACE page-lock only the whole pages INSIDE the caller's array (a page shared with a
-    // neighbour's memory must never be registered twice: msiren.hip, HostLock).  A first / last tile that reaches into such a page is read
-    // from a copy in the handle's own page-locked scratch instead: seam[0:1024] = tile 0 (if seam_head), seam[1024:2048] = tile seam_tail.
-    const float* seam = nullptr;
-    int seam_head = 0, seam_tail = 0x7fffffff;
 };
 
 // tile t of the call
-__device__ __forceinline__ const float* enc_tile(const EncoderParams& p, const float* tiles, int t) {
-    if (p.seam) {
-        if (t == 0 && p.seam_head) return p.seam;
-        if (t >= p.seam_tail) return p.seam + 1024;
-    }
-    return tiles + (size_t)t * 1024;
-}
+__device__ __forceinline__ const float* enc_tile(const EncoderParams&, const float* tiles, int t) { return tiles + (size_t)t * 1024; }
 
 __device__ __forceinline__ float leaky02(float x) { return x >= 0.f ? x : 0.2f * x; }
 

@@ -36,27 +36,6 @@ inline std::vector<HostChunk> pipelined_host_plan(int64_t B, int64_t first, int6
     return plan;
 }
 
-// Page arithmetic of a host call that reads the caller's tiles in place through a registration of the whole pages INSIDE the caller's
-// range (msiren.hip: HostLock::interior_view, msiren_forward_tiles_impl; EncoderParams::seam).
-struct InsidePages {
-    uintptr_t lo, hi;  // [lo, hi): the whole pages inside [a, a + bytes); lo >= hi: none
-};
-inline InsidePages inside_pages(uintptr_t a, size_t bytes, uintptr_t page = 4096) {
-    return {(a + page - 1) / page * page, (a + bytes) / page * page};
-}
-// Of B tiles of `tile_bytes` each, the ones that do not lie wholly inside the valid bytes [lo, hi) of the view: tiles [0, head) and
-// [tail_from, B).  ok: at most one at either end and at least one tile in between (what the kernels' seam scratch holds).
-struct SeamTiles {
-    int64_t head, tail_from;
-    bool ok;
-};
-inline SeamTiles seam_tiles(size_t lo, size_t hi, size_t tile_bytes, int64_t B) {
-    SeamTiles s{(int64_t)((lo + tile_bytes - 1) / tile_bytes), (int64_t)(hi / tile_bytes), false};
-    if (s.tail_from > B) s.tail_from = B;
-    s.ok = s.head <= 1 && B - s.tail_from <= 1 && s.tail_from > s.head;
-    return s;
-}
-
 // k-steps of one wave's stream, by section (H = 128 NPH, Z = 128 NPZ, L layers; with / without the encoder's and the Modulator's weights)
 struct EmStreamLayout {
     int c3, fc, zp, hl;        // k-steps of conv3 (this wave's K half), Linear(64, Z), the latent stage, the hidden chain

@@ -10,6 +10,5 @@ template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 3>(EmTailParams);
 template __global__ void latent_mods_f16x3_kernel<4, 1, 8, 3>(EmTailParams);
 template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 1>(EmTailParams);
 template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 2>(EmTailParams);
-template __global__ void encoder_conv_f16x3_kernel<0>(EncoderParams, const float*, em_u4*, float*);
 template __global__ void encoder_conv_f16x3_kernel<1>(EncoderParams, const float*, em_u4*, float*);
 }  // namespace msiren

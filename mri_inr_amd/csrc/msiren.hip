@@ -77,28 +77,18 @@ struct msiren_ctx {
         hipStream_t s = nullptr;
         DevBuf mods, modpad, latent, patches, keep, rec, queue, feat, plan;
         DevBuf cscratch;  // split-fp16 Modulator: the latent part of layers 1.., lane-private (encoder_modulator_f16x3.hip.h)
-        DevBuf mods2;  // a split call's second part: modulations written on the OTHER stream, read by this stream's trunk
-        hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // split call: start of the call -> helper stream; helper's prologue -> this stream
+        hipEvent_t ev_join = nullptr;  // a host call that pipelines itself: this stream's chunk has been enqueued
         msiren::PassQueue pq;  // host view of the never-reset pass counter (pass_queue.h)
     } sc[3];
     int cur = 0, nstreams = 1;
-    bool overlap = false;  // a host-pointer call is pipelining itself over both streams
     bool solo = false;     // a synchronous host-pointer call is running on ONE stream: nothing of this handle is to run beside its trunk
     // which split-fp16 trunk a launch takes: 0 = launch_trunk_f16x3's own rule; 1 = register-resident with room beside it
-    // (ring of 3); 2 = weight-stationary.  Set by forward_tiles_split around its two trunk launches.
+    // (ring of 3); 2 = weight-stationary.  Set per chunk by a host call that pipelines itself (host_plan.h).
     int trunk_force = 0;
     hipEvent_t trunk_after = nullptr;  // the next trunk launch waits for this event first (a pipelined host call: the weight-stationary
                                        // trunk of the last chunk behind the other stream's conditional launch, which cannot run beside it)
-    bool no_split = false;   // a host call that pipelines itself: its chunks are not cut again by forward_tiles_split
-    bool em_beside = false;  // the prologue being launched runs beside a trunk of this call (forward_tiles_split): shallow weight ring
-    // MSIREN_SPLIT_MIN: *_dev forward calls of at least this many tiles on a one-stream handle are cut in two (forward_tiles_split; 0 = never).
-    // Round 4 shipped 3200: the prologue was eight latency-bound launches, 1.3 of 17.2 ms at 64 slices, worth hiding behind the call's own first
-    // trunk.  With round 5's one-launch prologue (0.5 ms of L2-bound streaming that slows the trunk it runs beside by what it saves) every cut is
-    // within 0.5 % of the uncut call at 64 slices and 2-4 % behind it at 8 (profiles/r5/07_*): off by default; the mechanism and its tests stay.
-    int64_t split_min = 0;
-    int split_pct = 12;        // MSIREN_SPLIT_PCT: share of the first part, percent
-    int lin_tile_min = 1024;   // MSIREN_LINEAR_TILE_MIN: rows from which the Linear layers use the 32 x 32-tile kernel (0 = never)
-    bool lin_tile_env = false; // (set by the knob: then it holds for every layer width)
+    bool em_beside = false;  // the prologue being launched runs beside a trunk of this call (a pipelined host call's chunks): shallow weight ring
+    static constexpr int lin_tile_min = 1024;  // rows from which the exact-fp32 Linear layers use the 32 x 32-tile kernel (a quarter of it for >= 512 outputs)
     char last_trunk[96] = "";  // name of the trunk instance launched last (msiren_last_trunk_kernel)
     const int* plan = nullptr;  // device-side list of non-black patches in effect (slice pipeline only)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -118,31 +108,22 @@ struct msiren_ctx {
     // f16x3 domain guard: a word in host memory the trunk kernels set when a scaled modulation does not fit fp16
     volatile int* status_host = nullptr;
     int* status_dev = nullptr;
-    float* seam_host = nullptr;    // two tiles of page-locked scratch: the first / last tile of a host call whose tiles are read in place (EncoderParams::seam)
-    float* seam_dev = nullptr;
     unsigned range_epoch = 0;      // number of the split-fp16 trunk launch in flight (what it writes to its stream's flag word)
-    int tiling_fused = 1;          // MSIREN_TILING_FUSED: 0 = image_to_patches, black_flags, compact_flags and the pass counter's reset as separate stream operations, 1 = one launch in synchronous host calls, 2 = always
-    int cond_rerun = 1;            // MSIREN_RANGE_RERUN=0 (A/B knob: what the conditional launch costs): f16x3 launches go unguarded
     // Synchronous one-chunk msiren_forward_tiles calls (round 5): the host is going to wait for the stream anyway, so the trunk raises its flag in
     // HOST memory (status_host[8]) and the call looks at it after the wait -- no conditional launch (4.4 us of kernel + a launch gap per call);
-    // a flagged call enqueues the exact-fp32 trunk then and waits once more.  MSIREN_HOST_CHECK=0: the conditional launch, as on the asynchronous API.
-    int host_check = 1;
+    // a flagged call enqueues the exact-fp32 trunk then and waits once more (profiles/r5/12_*).  Asynchronous calls keep the conditional launch.
     bool host_check_now = false;   // set by the call for the launch_trunk it reaches
     struct { const float* mods = nullptr; int64_t B = 0; float* out = nullptr; unsigned epoch = 0; bool armed = false; } hc;
     int64_t range_events = 0;      // synchronisations that found the conditional exact-fp32 trunk had run, since create
     float* d_dump = nullptr;       // 256 floats: where lanes of the weight-stationary trunk that have nothing to store write
     int trace_host = 0;            // MSIREN_TRACE_HOST=1: msiren_forward_tiles prints the host-side timeline of the call (stderr)
-    int host_first_pct = 50;       // MSIREN_HOST_SPLIT: share (percent) of the batch in the first of the two chunks of a host call
-    int f16_ws = 1;                // the weight-stationary trunk runs single-stream launches (MSIREN_F16_WS=0: never; read at create)
+    int f16_ws = 1;                // the weight-stationary trunk runs single-stream launches (MSIREN_F16_WS=0: never; tests, A/B)
     float *d_bias16 = nullptr, *d_wout16 = nullptr, *d_s0t = nullptr;
     float mscale16[16] = {0};  // 16x16 kernel: factor of each layer's modulation row (the NEXT layer's weight scale, inverted)
     bool f16x3_ready = false;
     // single-product 16-bit trunk (MSIREN_PREC_BF16 / MSIREN_PREC_F16), H = 512
     void *d_woutx1 = nullptr, *d_wpx1n = nullptr;  // last_layer.weight (fp16); weight stream of siren_trunk_x1n.hip.h
     void* d_wpx1w = nullptr;       // weight stream of siren_trunk_x1w.hip.h (weight-stationary: 64 KB per layer, N-pass and wave)
-    int x1_ws = 1;                 // MSIREN_X1_WS=0: the register-resident kernel (A/B knob, read at create)
-    int x1_grid = 0;               // MSIREN_X1_GRID=n: cap on the config-5 trunk's grid (experiments)
-    int x1_balance = 1;            // MSIREN_X1_BALANCE=0: the weight-stationary config-5 trunk on every CU (A/B knob; x1w_balanced_grid)
     int lds_attr_x1w = 0;
 
     float* d_bias32x1 = nullptr;   // bias rows: fp32, in revolutions x the layer's weight scale
@@ -150,23 +131,11 @@ struct msiren_ctx {
     float winvx1[64] = {0};
     bool x1_ready = false;
     int num_cus = 256;
-    // diagnostic knobs ("Environment knobs"): read ONCE, at msiren_create -- not on the launch path
-    int cus_limit = 256;       // MSIREN_GRID: cap on the persistent grids
-    int ring_force = 0;        // MSIREN_F16_RING: 3 / 4 forces the weight ring depth of the register-resident trunk
-    int half_allowed = 1;      // MSIREN_F16_HALF=0: never use the half-unit instance
-    // MSIREN_HOST_REGISTER=1: the pageable tiles of a one-chunk host call are page-locked for the call's duration (the whole pages inside them) and
-    // read in place: 30 us per slice faster -- and OFF by default: with per-call hipHostRegister / hipHostUnregister in the process the GPU suite
-    // died about one run in three with "Memory access fault by GPU ... Reason: Unknown" at a page-aligned HOST address inside a later
-    // copy of the runtime's own (hipMemcpy from a std::vector in msiren_commit_weights, twice; a pageable download, once), each time shortly
-    // after the tests that register from two threads; without it, never (profiles/r5/14_*).  Registering only pages no other buffer can share
-    // did not cure it, so the cause is below this library; what is in place by default is page-locked memory only (see HostLock).
-    int host_register = 0;
-    int zc_out = 1, zc_in = 1;  // MSIREN_ZC_OUT / MSIREN_ZC_IN: kernels write / read page-locked caller buffers in place (A/B knobs)
-    int recon_zc = 1;           // MSIREN_RECON_ZC: host slice -> slice call on page-locked buffers: 1 = reconstruction stored in place, 2 = image read in place
+    // environment knobs (the whole list): read ONCE, at msiren_create -- not on the launch path
+    int half_allowed = 1;      // MSIREN_F16_HALF=0: never use the half-unit instance (tests: instance selection)
     int host_pipe_min = 2400;  // MSIREN_HOST_PIPE_MIN: tiles from which a host call cuts itself into chunks (below: one chunk, buffers in place; profiles/r5/04_*)
-    int host_first = 112, host_piece = 400;  // MSIREN_HOST_FIRST / MSIREN_HOST_PIECE: tiles in the first / the further chunks of a pipelined host call
-    int host_chunks = 0;       // MSIREN_HOST_CHUNKS: chunks a synchronous host call cuts itself into (0 = default)
-    unsigned queue_start = 0;  // MSIREN_QUEUE_START: initial value of the never-reset pass counters
+    static constexpr int host_first = 112, host_piece = 400;  // tiles in the first / the further chunks of a pipelined host call (host_plan.h)
+    unsigned queue_start = 0;  // MSIREN_QUEUE_START: initial value of the never-reset pass counters (tests: wrap-around)
     // modulator: transposed weights so that consecutive threads read consecutive outputs
     float *d_modw = nullptr, *d_modb = nullptr, *d_modw_rm = nullptr;  // transposed / as stored (row-major)
     // encoder
@@ -175,15 +144,12 @@ struct msiren_ctx {
     // encoder tail + Modulator in split-fp16 arithmetic, one launch (encoder_modulator_f16x3.hip.h); every precision but fp32
     void* d_emw = nullptr;         // packed weight streams of the four waves
     void* d_emc2 = nullptr;        // conv2's MFMA A fragments
-    int em_conv_mfma = 1;          // MSIREN_CONV_MFMA=0: conv2 on the VALU (A/B knob, read at create)
     float* d_embias = nullptr;     // [conv3 64][fc Z][modulator L x H]
     float em_winv_c3 = 1.f, em_winv_fc = 1.f, em_winv_z[64] = {0}, em_winv_h[64] = {0};
     int em_wave_stride = 0, em_zp_start = 0;
     bool em_enc = false, em_mod = false;  // which halves of the stream are packed (the checkpoint's key set decides)
-    int em_prefetch = 1;           // MSIREN_EM_PREFETCH=0: no L2-prefetch workgroups in the prologue's grid (A/B knob)
-    int em_depth = 0;              // MSIREN_EM_DEPTH=2|4|8: force the weight-ring depth of the split-fp16 prologue (A/B knob)
-    int ws_two = 0;                // MSIREN_WS_TWO=1: the weight-stationary trunk on two-stream handles as well (experiment)
-    int em_enabled = 1;            // MSIREN_PROLOGUE_F16X3=0: the exact-fp32 launches per layer (A/B knob, read at create)
+    int em_depth = 0;              // MSIREN_EM_DEPTH=2|4|8: force the weight-ring depth of the split-fp16 prologue (tests: same bits at every depth)
+    int em_enabled = 1;            // MSIREN_PROLOGUE_F16X3=0: the exact-fp32 launches per layer on a split-fp16 handle (tests, A/B)
     float* d_foldw = nullptr;  // (S,S) overlap-add weights
     // workspaces
     DevBuf ws_out, ws_tiles, ws_in, ws_img;  // staging of the host-pointer entry points
@@ -449,9 +415,9 @@ int pack_trunk_x1(msiren_ctx* h) {
     const bool bf = h->cfg.precision == MSIREN_PREC_BF16;
     if (!(h->cfg.precision == MSIREN_PREC_BF16 || h->cfg.precision == MSIREN_PREC_F16)) return 0;
     // (the kernel launch_trunk_x1_kernel will pick: weight-stationary from 3 layers on, depths 2..11; register-resident 2..10)
-    const int lds_need = (h->x1_ws && L >= 3) ? msiren::X1wLds::total(L) : msiren::X1nLds<3>::total(L);
+    const int lds_need = L >= 3 ? msiren::X1wLds::total(L) : msiren::X1nLds<3>::total(L);
     if (H != 512 || L < 2 || L > 65 || lds_need > 160 * 1024)
-        return fail(MSIREN_E_INVALID, "precision bf16/f16 (single-product trunk) needs dim_hidden = 512 and 2 <= num_layers <= 11 (10 with MSIREN_X1_WS=0): its tables must fit the 160 KB LDS; got H=%d L=%d", H, L);
+        return fail(MSIREN_E_INVALID, "precision bf16/f16 (single-product trunk) needs dim_hidden = 512 and 2 <= num_layers <= 11: its tables must fit the 160 KB LDS; got H=%d L=%d", H, L);
     const double two_pi = 6.283185307179586476925286766559;
     const double c = (double)h->cfg.w0 / two_pi;
     std::vector<uint16_t> wpn((size_t)(L - 1) * 16 * 16 * 2 * 64 * 8), wout(512, 0);  // chunk (l, t) = [16 k-steps][2 sub-tiles][64 lanes][8]
@@ -684,11 +650,9 @@ int pack_prologue_f16x3(msiren_ctx* h) {
                     for (int j = 0; j < 8; ++j) {
                         const int s2 = (msiren::EM_C3_KSTEPS / 2) * (wave >> 1) + ks, f = 32 * (wave & 1) + 16 * t + (lane & 15);
                         int k;  // torch's flattened (channel, position) index of element (k-step s2, q = lane >> 4, j) of the conv kernel's images
-                        if (h->em_conv_mfma) {
+                        {
                             const int cw = s2 >> 4, cl = 4 * (s2 & 15) + (lane >> 4);  // the conv kernel's (wave, lane) that stored this piece
                             k = (16 * (cw & 1) + 4 * (cl >> 4) + (j & 3)) * 64 + 16 * (2 * (cw >> 1) + (j >> 2)) + (cl & 15);
-                        } else {
-                            k = (8 * (s2 >> 4) + j) * 64 + 4 * (s2 & 15) + (lane >> 4);
                         }
                         put(wave, ks, t, lane, j, std::ldexp((double)W3[(size_t)f * 2048 + k], a3));
                     }
@@ -927,7 +891,7 @@ int launch_trunk_f16x3w(msiren_ctx* h, const float* mods_dev, int64_t B, float* 
         p.div_m = (unsigned)(((1ULL << p.div_k) + (unsigned)upp - 1) / (unsigned)upp);
     }
     // small batches: one pass of 2 units per workgroup (latency); otherwise one workgroup per CU
-    const int grid = (int)std::min<int64_t>(h->cus_limit, (units + 1) / 2);
+    const int grid = (int)std::min<int64_t>(h->num_cus, (units + 1) / 2);
     const msiren::WsSchedule sch = msiren::ws_schedule(units, grid);
     int rc = queue_for_launch(h, sch.npasses(), &p.pass_counter, &p.pass_base);
     if (rc) return rc;
@@ -956,13 +920,13 @@ bool ws_capable(msiren_ctx* h, int64_t B) {
     static_assert(msiren::WsLds<4>::total(msiren::WS_MAX_L) <= 160 * 1024, "unit images + tables of the deepest supported model must fit the LDS");
     return h->f16_ws && h->L >= msiren::WS_MIN_L && h->L <= msiren::WS_MAX_L && (int64_t)h->L * B * 256 * 4 < (1LL << 32);
 }
-bool use_f16x3w(msiren_ctx* h, int64_t B) { return ws_capable(h, B) && (h->nstreams == 1 || h->solo || h->ws_two) && !h->overlap; }
+bool use_f16x3w(msiren_ctx* h, int64_t B) { return ws_capable(h, B) && (h->nstreams == 1 || h->solo); }
 
 int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev) {
     const int upp_ = (h->P + 31) / 32;
     // (small batches of depth-5 models keep the half-unit instance: twice the waves, lower latency)
     if (h->trunk_force == 2 ||
-        (h->trunk_force == 0 && use_f16x3w(h, B) && !(h->L == 5 && h->half_allowed && !h->plan && B * upp_ <= 2 * (int64_t)h->cus_limit)))
+        (h->trunk_force == 0 && use_f16x3w(h, B) && !(h->L == 5 && h->half_allowed && !h->plan && B * upp_ <= 2 * (int64_t)h->num_cus)))
         return launch_trunk_f16x3w(h, mods_dev, B, out_dev);
     msiren::TrunkF16Params p{};
     p.grid = h->d_grid;
@@ -986,13 +950,12 @@ int launch_trunk_f16x3(msiren_ctx* h, const float* mods_dev, int64_t B, float* o
     if (units > 0x3fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     // R = 3 leaves ~35 KB of LDS per CU free, enough for an encoder / modulator workgroup of the NEXT
     // call (other stream) to run beside the persistent trunk workgroup; R = 4 fills the CU.
-    int ring = ((h->nstreams > 1 && !h->solo) || h->overlap || h->trunk_force == 1) ? 3 : 4;
+    int ring = ((h->nstreams > 1 && !h->solo) || h->trunk_force == 1) ? 3 : 4;
     // depths other than 5 run the loop form of the kernel: with a ring of 3 hipcc gives it all 512 registers (and 188 bytes of
     // scratch per lane), so nothing could run beside it anyway -- the ring of 4 has neither (164 + 240 registers)
     if (ring == 3 && h->L != 5) ring = 4;
-    if (h->ring_force) ring = h->ring_force;
     const bool r4 = ring >= 4 && msiren::F16Lds<4>::total(h->L) <= 160 * 1024;
-    const int cus = h->cus_limit;
+    const int cus = h->num_cus;
 
     // One launch of a piece of the batch: units [base, base + count) of `per_wave` coordinates each.  The pass queue
     // (workgroup g starts with pass g, further passes come from the counter) is claimed per launch.
@@ -1046,11 +1009,11 @@ int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_
     if (units > 0x7fffffffLL) return fail(MSIREN_E_INVALID, "batch too large for one launch: B=%lld", (long long)B);
     p.total_units = (int)units;
     p.plan = h->plan;
-    const bool ws = h->x1_ws && h->L >= 3;
+    const bool ws = h->L >= 3;
     // (one-stream handles: the balanced grid -- the same rounds on fewer CUs, 1 % faster alone; two streams: every CU, so that the
     //  next call's trunk can start in the half-empty last round -- measured 111.2 against 109.3 Mpixel/s, profiles/r4/09_*)
-    const int cus_x1 = h->x1_grid > 0 ? std::min(h->x1_grid, h->num_cus) : h->num_cus;
-    const bool balance = ws && h->x1_balance && (h->nstreams == 1 || h->solo);
+    const int cus_x1 = h->num_cus;
+    const bool balance = ws && (h->nstreams == 1 || h->solo);
     const int grid = balance ? msiren::x1w_balanced_grid(units, cus_x1) : (int)std::min<int64_t>(cus_x1, (units + 3) / 4);
     // (the weight-stationary kernel lays its passes out itself: x1w_schedule, 4-unit passes and a last round of 2-unit ones)
     msiren::X1wSchedule sch = msiren::x1w_schedule(units, grid);
@@ -1065,7 +1028,7 @@ int launch_trunk_x1(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_
 int launch_trunk_x1_kernel(msiren_ctx* h, const msiren::TrunkX1Params& p0, int grid) {
     const bool bf = h->cfg.precision == MSIREN_PREC_BF16, mor = h->cfg.activation == MSIREN_ACT_MORLET, res = h->cfg.residual != 0;
     msiren::TrunkX1Params p = p0;
-    if (h->x1_ws && h->L >= 3) {  // weight-stationary (siren_trunk_x1w.hip.h; its layer pipeline needs a hidden layer before the final one)
+    if (h->L >= 3) {  // weight-stationary (siren_trunk_x1w.hip.h; its layer pipeline needs a hidden layer before the final one)
         p.wp = (const unsigned short*)h->d_wpx1w;
         const int lds = msiren::X1wLds::total(h->L);
 #define MSIREN_X1W_LAUNCH(BF, A, RS)                                                                 \
@@ -1191,7 +1154,6 @@ int launch_trunk(msiren_ctx* h, const float* mods_dev, int64_t B, float* out_dev
         int rc = h->x1_ready ? launch_trunk_x1(h, mods_dev, B, out_dev) : launch_trunk_f16x3(h, mods_dev, B, out_dev);
         if (rc) return rc;
         if ((rc = profile_end(h, e1, B * h->P))) return rc;
-        if (!h->cond_rerun) return 0;
         if (h->host_check_now && !h->x1_ready) {  // (the caller looks at the flag in host memory behind its wait for the stream)
             h->hc.mods = mods_dev;
             h->hc.B = B;
@@ -1252,10 +1214,10 @@ int launch_linear(msiren_ctx* h, const msiren::ModulatorMfmaParams& mp) {
     hipStream_t s = h->sc[h->cur].s;
     // (default threshold: 1024 rows; a quarter of it for layers of >= 512 outputs -- at 400 rows the 16 x 16 kernel launches 800 workgroups
     //  per 512-wide layer and takes 10.8 us, the tiled one is 1.7 % of a config-5 step faster; 256-wide layers: 2.7 % slower.  Same bits.)
-    const int tile_min = h->lin_tile_env || mp.H < 512 ? h->lin_tile_min : h->lin_tile_min / 4;
+    const int tile_min = mp.H < 512 ? h->lin_tile_min : h->lin_tile_min / 4;
     // (the tiled kernel addresses rows with 32-bit element offsets: beyond 2^32 elements per operand the 16 x 16 kernel, same bits)
     const bool fits32 = (uint64_t)mp.B * (uint64_t)std::max(std::max(mp.Z, mp.H), mp.Kh) < (1ULL << 32);
-    if (h->lin_tile_min > 0 && mp.B >= tile_min && fits32) {
+    if (mp.B >= tile_min && fits32) {
         dim3 grid((unsigned)((mp.B + 31) / 32), (unsigned)((mp.H + 31) / 32));
         hipLaunchKernelGGL((msiren::linear_mfma_tile_kernel<2, 2>), grid, dim3(256), 0, s, mp);
     } else {
@@ -1282,8 +1244,7 @@ int launch_prologue_f16x3_t(msiren_ctx* h, const float* tiles_dev, const float* 
         p.feat_inv = (const float*)((const char*)c.feat.p + (size_t)rows16 * 2048 * 4 + msiren::EM_MAX_DEPTH * 2048);
         h->enc.plan = h->plan;
         float* const finv = (float*)((char*)c.feat.p + (size_t)rows16 * 2048 * 4 + msiren::EM_MAX_DEPTH * 2048);
-        if (h->em_conv_mfma) hipLaunchKernelGGL(msiren::encoder_conv_f16x3_kernel<1>, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, (msiren::em_u4*)c.feat.p, finv);
-        else hipLaunchKernelGGL(msiren::encoder_conv_f16x3_kernel<0>, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, (msiren::em_u4*)c.feat.p, finv);
+        hipLaunchKernelGGL(msiren::encoder_conv_f16x3_kernel<1>, dim3((unsigned)B), dim3(256), 0, c.s, h->enc, tiles_dev, (msiren::em_u4*)c.feat.p, finv);
         HIPCHK(hipGetLastError());
     }
     if (mods_dev) {
@@ -1309,12 +1270,12 @@ int launch_prologue_f16x3_t(msiren_ctx* h, const float* tiles_dev, const float* 
     const int lds = msiren::em_tail_lds_bytes<NPH, NPZ>();
     // ring depth 4 (more weight fragments in flight per wave) where the workgroups have their CUs to themselves; depth 2 (<= 96
     // registers, 33 KB of LDS) where they run beside the register-resident trunk of the other stream or many to a CU.  Same bits.
-    const bool alone = (h->nstreams == 1 || h->solo) && !h->overlap && !h->em_beside;
+    const bool alone = (h->nstreams == 1 || h->solo) && !h->em_beside;
     int depth = alone ? (nblk <= (int64_t)h->num_cus ? 8 : 4) : 2;
     if (h->em_depth) depth = h->em_depth;
     // latency sizes of the H = 256 model: 64 more workgroups (8 per XCD) that only pull the 2.9 MB weight stream into the L2s (EmTailParams)
     p.row_blocks = (int)nblk;
-    if (NPH == 2 && h->em_prefetch && alone && nblk <= 64 && tiles_dev && mods_dev) {
+    if (NPH == 2 && alone && nblk <= 64 && tiles_dev && mods_dev) {
         p.pf_blocks = 64;
         p.pf_lines = (unsigned)(((size_t)h->em_wave_stride * 4 * 16 / 8 + 1023) / 1024);
     }
@@ -1450,60 +1411,7 @@ int forward_latent_dev(msiren_ctx* h, const float* z_dev, int64_t B, float* out_
     return launch_trunk(h, mods, B, out_dev);
 }
 
-// ---- large calls: hide the encoder + modulator of most of the batch behind the trunk of its first part (opt-in since round 5) ----------------
-// One big call cannot overlap with itself: its prologue (conv1/conv2, conv3, Linear, L Modulator layers -- 20 us per
-// 400 tiles at throughput sizes) ran in front of a trunk that then had the chip to itself: 1.3 of 17.2 ms for 64 slices.
-// The weight-stationary trunk leaves no room beside it, the register-resident one does.  So a call of
-// >= split_min tiles is cut in two:
-//     call's stream:   E0 | prologue(part 0) | register-resident trunk(part 0) | wait E1 | weight-stationary trunk(part 1)
-//     other stream:    wait E0 | prologue(part 1) ........................... E1
-// part 0 (split_pct of the batch) is sized so that its trunk outlasts part 1's prologue running beside it.  Patches are
-// independent and both trunks give the same bits (tests/test_gpu_ws.py), so the cut does not change results.  The
-// modulations of part 1 cross streams (mods2 of the call's stream, written on the other one); latent and conv features
-// stay on the stream that produces and consumes them.  The call still "happens on its stream": inputs are read and
-// outputs written by work that the stream's tail depends on.
-bool use_split(msiren_ctx* h, int64_t B) {
-    return h->split_min > 0 && B >= h->split_min && (h->nstreams == 1 || h->solo) && !h->plan && !h->overlap && !h->no_split && h->L == 5 && use_f16x3(h) &&
-           !h->x1_ready && h->have_encoder && h->have_modulator && h->Z % 16 == 0 && ws_capable(h, B);
-}
-
-int forward_tiles_split(msiren_ctx* h, const float* tiles_dev, int64_t B, float* out_dev) {
-    const int a = h->cur, b = a == 0 ? 1 : 0;
-    auto& A = h->sc[a];
-    auto& O = h->sc[b];
-    int64_t B0 = (B * h->split_pct / 100 + 15) / 16 * 16;
-    B0 = std::max<int64_t>(16, std::min<int64_t>(B0, B - 16));
-    const int64_t B1 = B - B0;
-    int rc;
-    if ((rc = ensure(h, A.latent, (size_t)B0 * h->Z * sizeof(float))) || (rc = ensure(h, A.mods, (size_t)h->L * B0 * h->H * sizeof(float))) ||
-        (rc = ensure(h, O.latent, (size_t)B1 * h->Z * sizeof(float))) || (rc = ensure(h, A.mods2, (size_t)h->L * B1 * h->H * sizeof(float))))
-        return rc;
-    if (!A.ev_fork) HIPCHK(hipEventCreateWithFlags(&A.ev_fork, hipEventDisableTiming));
-    if (!A.ev_join) HIPCHK(hipEventCreateWithFlags(&A.ev_join, hipEventDisableTiming));
-    struct Restore {  // the launchers below address the stream through h->cur and the trunk through h->trunk_force
-        msiren_ctx* h;
-        int cur;
-        ~Restore() { h->cur = cur; h->trunk_force = 0; }
-    } restore{h, a};
-    HIPCHK(hipEventRecord(A.ev_fork, A.s));
-    HIPCHK(hipStreamWaitEvent(O.s, A.ev_fork, 0));
-    h->cur = b;  // part 1's prologue first: it is the long one, and nothing it needs is still to come
-    h->em_beside = true;
-    rc = launch_encoder_modulator(h, tiles_dev + (size_t)B0 * h->O * h->O, B1, (float*)O.latent.p, (float*)A.mods2.p);
-    h->em_beside = false;
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(A.ev_join, O.s));
-    h->cur = a;
-    if ((rc = launch_encoder_modulator(h, tiles_dev, B0, (float*)A.latent.p, (float*)A.mods.p))) return rc;
-    h->trunk_force = 1;
-    if ((rc = launch_trunk(h, (const float*)A.mods.p, B0, out_dev))) return rc;
-    HIPCHK(hipStreamWaitEvent(A.s, A.ev_join, 0));
-    h->trunk_force = 2;
-    return launch_trunk(h, (const float*)A.mods2.p, B1, out_dev + (size_t)B0 * h->P);
-}
-
 int forward_tiles_dev(msiren_ctx* h, const float* tiles_dev, int64_t B, float* out_dev) {
-    if (use_split(h, B)) return forward_tiles_split(h, tiles_dev, B, out_dev);
     int rc = ensure(h, h->sc[h->cur].latent, (size_t)B * h->Z * sizeof(float));
     if (rc) return rc;
     rc = ensure(h, h->sc[h->cur].mods, (size_t)h->L * B * h->H * sizeof(float));
@@ -1514,8 +1422,20 @@ int forward_tiles_dev(msiren_ctx* h, const float* tiles_dev, int64_t B, float* o
     return launch_trunk(h, mods, B, out_dev);
 }
 
-// Device address of page-locked host memory (msiren_host_alloc, hipHostMalloc / hipHostRegister of any origin, e.g. a pinned torch tensor);
-// nullptr for ordinary pageable memory.  With it a kernel can read / write the caller's buffer itself -- no copy, no staging.
+// ---- the caller's host buffers -------------------------------------------------------------------------------------------
+// A host range handed to a synchronous entry point is one of three things, decided per call from what the HIP runtime says about it
+// (nothing is cached, nothing of the caller's is ever registered or unregistered by this library -- round 5's per-call hipHostRegister
+// of pageable buffers is gone: profiles/r6/01_*):
+//   HOST_PINNED    the WHOLE range lies inside ONE page-locked allocation (msiren_host_alloc, hipHostMalloc, a caller's hipHostRegister,
+//                  a pinned torch tensor): kernels and DMA copies work on it in place through `dev`;
+//   HOST_PAGEABLE  no byte of it is page-locked as far as its two ends tell: copied by the runtime (hipMemcpyAsync on the pointer);
+//   HOST_PARTIAL   it begins or ends inside a page-locked allocation that does not contain all of it (a caller's own partial
+//                  hipHostRegister; two registrations with pageable bytes between them): the runtime refuses a copy whose range leaves
+//                  the registration it starts in ("invalid argument": tools/soak.py found it in round 5) and a kernel would fault on the
+//                  pageable part, so the call goes through a page-locked bounce buffer of its own -- rare, slow, correct.
+enum HostKind { HOST_PAGEABLE = 0, HOST_PINNED = 1, HOST_PARTIAL = 2 };
+
+// Device address of page-locked host memory; nullptr for ordinary pageable memory.
 void* host_pinned_dev(const void* p) {
     hipPointerAttribute_t a{};
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {
@@ -1525,156 +1445,26 @@ void* host_pinned_dev(const void* p) {
     return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
 }
 
-// A caller's host buffer for the duration of one call, decided here under ONE process-wide lock:
-//   * full device view (device_view): page-locked memory of the caller's own (msiren_host_alloc, a pinned torch tensor, ...), used as it is;
-//   * interior view (interior_view; INPUT tiles only): ordinary pageable memory is page-locked for the call's duration (hipHostRegister, 4-6 us)
-//     -- but only the WHOLE PAGES INSIDE the caller's range.  On this platform a registration maps pages at their own virtual address into
-//     the GPU's address space, so two registrations that share a page (a numpy array begins 16 bytes into a page: its first page also holds
-//     the tail of its neighbour on the heap, which the runtime may have pinned for a copy of its own, or another thread's call may have
-//     registered) share ONE mapping -- and whoever unregisters first takes the page away from the other.  Round 5 registered whole ranges at
-//     first; the GPU suite then died about one run in four with "Memory access fault by GPU ... on address <page-aligned host address>"
-//     inside a later runtime copy (profiles/r5/14_*).  Pages that lie wholly inside the caller's range can hold nobody else's bytes; the
-//     first / last tile that reaches into a shared page goes through the handle's own page-locked scratch (EncoderParams::seam).
-//     Registrations are reference-counted: handles in different threads that are handed the same array (or windows inside it) share one;
-//   * runtime copies (hipMemcpyAsync on the caller's pointer): the range is entered in a list of ranges being copied, and NO registration is
-//     made over such a range while it is there -- the runtime treats a pointer inside a registration as page-locked (the registration would
-//     end under the copy) and refuses a copy whose range leaves the registration ("invalid argument": tools/soak.py found it);
-//   * bounce buffer (partial()): the range is page-locked in PART -- a neighbour's call on an overlapping window, a caller's own partial
-//     hipHostRegister -- so none of the above is safe on it: the call copies it by CPU into / out of page-locked memory of its own.
-struct HostView {
-    void* dev = nullptr;     // device address of the range's FIRST byte (nullptr: no view)
-    size_t lo = 0, hi = 0;   // bytes [lo, hi) of the range may be touched through it
-};
+HostKind host_range_kind(const void* host, size_t bytes, void** dev) {
+    *dev = nullptr;
+    if (!host || !bytes) return HOST_PAGEABLE;
+    void* const d = host_pinned_dev(host);
+    if (!d) return (bytes > 1 && host_pinned_dev((const char*)host + bytes - 1)) ? HOST_PARTIAL : HOST_PAGEABLE;
+    // both ends inside page-locked memory is not enough (two allocations, pageable bytes in between; on this platform the device
+    // address of page-locked memory usually EQUALS its host address, so "d_last == d + bytes - 1" proves nothing): the allocation
+    // that holds the first byte must hold the last one -- base and size of it from the runtime.
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)d) != hipSuccess) {
+        (void)hipGetLastError();
+        return HOST_PARTIAL;  // (the runtime cannot name the allocation: do not trust the range)
+    }
+    if ((uintptr_t)d + bytes > (uintptr_t)base + size) return HOST_PARTIAL;
+    *dev = d;
+    return HOST_PINNED;
+}
 
-class HostLock {
-    struct Entry { size_t bytes; void* dev; int refs; };
-    static constexpr uintptr_t PAGE = 4096;
-    static std::mutex& mu() { static std::mutex m; return m; }
-    static std::map<uintptr_t, Entry>& table() { static std::map<uintptr_t, Entry> t; return t; }
-    static std::vector<std::pair<uintptr_t, size_t>>& copies() { static std::vector<std::pair<uintptr_t, size_t>> c; return c; }
-    uintptr_t base_ = 0;  // key of the registration this object holds a reference to (0: none)
-    uintptr_t copy_a_ = 0;
-    size_t copy_n_ = 0;   // the range this object has entered in copies() (0: none)
-    bool partial_ = false;
-
-    // 0: no registration of ours touches [a, a + bytes); 1: one contains it (`it`); 2: one covers part of it
-    static int ours(uintptr_t a, size_t bytes, std::map<uintptr_t, Entry>::iterator& hit) {
-        auto it = table().upper_bound(a);
-        if (it != table().end() && it->first < a + bytes) return 2;
-        if (it != table().begin()) {
-            --it;
-            if (a >= it->first && a + bytes <= it->first + it->second.bytes) { hit = it; return 1; }
-            if (it->first + it->second.bytes > a) return 2;
-        }
-        return 0;
-    }
-    // the caller's own page-locked memory: 1 = all of the range (dev set), 2 = part of it, 0 = none
-    static int foreign(const void* host, size_t bytes, void*& dev) {
-        void* const d_last = bytes > 1 ? host_pinned_dev((const char*)host + bytes - 1) : nullptr;
-        if (void* d = host_pinned_dev(host)) {
-            if (bytes <= 1 || d_last == (char*)d + bytes - 1) { dev = d; return 1; }
-            return 2;
-        }
-        return d_last ? 2 : 0;
-    }
-    void enter_copy(uintptr_t a, size_t bytes) {
-        copies().emplace_back(a, bytes);
-        copy_a_ = a;
-        copy_n_ = bytes;
-    }
-
-public:
-    // the range is page-locked in PART (by a neighbour's call, or by the caller): neither a device view nor a runtime copy is safe on it --
-    // hipMemcpy refuses a range that begins inside a registration and ends outside it -- so the call goes through a bounce buffer
-    bool partial() const { return partial_; }
-    HostLock() = default;
-    HostLock(const HostLock&) = delete;
-    HostLock& operator=(const HostLock&) = delete;
-    ~HostLock() {
-        if (!base_ && !copy_n_) return;
-        std::lock_guard<std::mutex> g(mu());
-        if (base_) {
-            auto it = table().find(base_);
-            if (it != table().end() && --it->second.refs == 0) {
-                (void)hipHostUnregister((void*)base_);
-                table().erase(it);
-            }
-        }
-        if (copy_n_) {
-            auto& c = copies();
-            for (size_t i = 0; i < c.size(); ++i)
-                if (c[i].first == copy_a_ && c[i].second == copy_n_) {
-                    c[i] = c.back();
-                    c.pop_back();
-                    break;
-                }
-        }
-    }
-    // Device address of the WHOLE range -- the caller's own page-locked memory, or a range inside a registration of ours -- or nullptr: then
-    // partial() says whether the caller may copy from / to it through the runtime (the range is entered in copies()) or must bounce.  Never registers.
-    void* device_view(const void* host, size_t bytes) {
-        const uintptr_t a = (uintptr_t)host;
-        std::lock_guard<std::mutex> g(mu());
-        std::map<uintptr_t, Entry>::iterator it;
-        const int o = ours(a, bytes, it);
-        if (o == 1) {
-            it->second.refs++;
-            base_ = it->first;
-            return (char*)it->second.dev + (a - it->first);
-        }
-        if (o == 2) { partial_ = true; return nullptr; }
-        void* d = nullptr;
-        const int f = foreign(host, bytes, d);
-        if (f == 1) return d;
-        if (f == 2) { partial_ = true; return nullptr; }
-        enter_copy(a, bytes);
-        return nullptr;
-    }
-    // As device_view, but pageable memory is page-locked for the call: the whole pages inside the range, if they are at least `min_bytes`.
-    HostView interior_view(const void* host, size_t bytes, size_t min_bytes) {
-        const uintptr_t a = (uintptr_t)host;
-        const msiren::InsidePages in = msiren::inside_pages(a, bytes, PAGE);  // (host_plan.h: unit-tested on the CPU)
-        const uintptr_t lo = in.lo, hi = in.hi;
-        std::lock_guard<std::mutex> g(mu());  // (one critical section: of two threads that come with the same new buffer, the second finds the first's entry)
-        std::map<uintptr_t, Entry>::iterator it;
-        int o = ours(a, bytes, it);
-        if (o == 1) {
-            it->second.refs++;
-            base_ = it->first;
-            return {(char*)it->second.dev + (a - it->first), 0, bytes};
-        }
-        if (o == 2 && hi > lo && ours(lo, hi - lo, it) == 1) {  // (the same array once more: its inside pages are registered already)
-            it->second.refs++;
-            base_ = it->first;
-            return {(char*)it->second.dev - (it->first - a), (size_t)(lo - a), (size_t)(hi - a)};  // (lo >= it->first: the view's first valid byte is lo)
-        }
-        if (o == 2) { partial_ = true; return {}; }
-        void* d = nullptr;
-        const int f = foreign(host, bytes, d);
-        if (f == 1) return {d, 0, bytes};
-        if (f == 2) { partial_ = true; return {}; }
-        bool being_copied = false;
-        for (const auto& c : copies()) being_copied = being_copied || (c.first < a + bytes && a < c.first + c.second);
-        if (!being_copied && hi > lo && hi - lo >= min_bytes) {
-            if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
-                void* dl = nullptr;
-                if (hipHostGetDevicePointer(&dl, (void*)lo, 0) == hipSuccess && dl) {
-                    table()[lo] = Entry{(size_t)(hi - lo), dl, 1};
-                    base_ = lo;
-                    return {(char*)dl - (lo - a), (size_t)(lo - a), (size_t)(hi - a)};
-                }
-                (void)hipGetLastError();
-                (void)hipHostUnregister((void*)lo);
-            } else {
-                (void)hipGetLastError();
-            }
-        }
-        enter_copy(a, bytes);
-        return {};
-    }
-};
-
-// Page-locked memory of one call's own (the bounce buffer of a range that is page-locked in part)
+// Page-locked memory of one call's own (the bounce buffer of a HOST_PARTIAL range)
 struct HostBounce {
     void* p = nullptr;
     HostBounce() = default;
@@ -1690,44 +1480,55 @@ struct HostBounce {
     }
 };
 
-// A caller's buffer that a synchronous call copies from / to through the runtime: entered in HostLock's list for the call's duration (no
-// registration is made over it meanwhile), a neighbour's registration around it kept alive, a range that is page-locked in part bounced.
+// A caller's input / output buffer of one synchronous call: `as<T>()` is what the call's copies use (the caller's pointer, or the
+// bounce buffer of a HOST_PARTIAL range), `dev<T>()` the device view of a HOST_PINNED range (nullptr otherwise: no in-place access).
 class HostSrc {
-    HostLock lock_;
     HostBounce b_;
     const void* p_;
+    void* dev_ = nullptr;
     bool ok_ = true;
 
 public:
     HostSrc(const void* host, size_t n) : p_(host) {
         if (!host || !n) return;
-        (void)lock_.device_view(host, n);
-        if (!lock_.partial()) return;
-        if (b_.alloc(n)) { std::memcpy(b_.p, host, n); p_ = b_.p; } else ok_ = false;
+        if (host_range_kind(host, n, &dev_) != HOST_PARTIAL) return;
+        if (b_.alloc(n)) { std::memcpy(b_.p, host, n); p_ = b_.p; dev_ = host_pinned_dev(b_.p); } else ok_ = false;
     }
     bool ok() const { return ok_; }
     template <typename T> const T* as() const { return (const T*)p_; }
+    template <typename T> const T* dev() const { return (const T*)dev_; }
 };
 class HostDst {
-    HostLock lock_;
     HostBounce b_;
     void* user_;
     void* p_;
+    void* dev_ = nullptr;
     size_t n_;
     bool ok_ = true;
 
 public:
     HostDst(void* host, size_t n) : user_(host), p_(host), n_(n) {
         if (!host || !n) return;
-        (void)lock_.device_view(host, n);
-        if (!lock_.partial()) return;
-        if (b_.alloc(n)) p_ = b_.p; else ok_ = false;
+        if (host_range_kind(host, n, &dev_) != HOST_PARTIAL) return;
+        if (b_.alloc(n)) { p_ = b_.p; dev_ = host_pinned_dev(b_.p); } else ok_ = false;
     }
     bool ok() const { return ok_; }
     template <typename T> T* as() const { return (T*)p_; }
+    template <typename T> T* dev() const { return (T*)dev_; }
     void finish() const { if (b_.p) std::memcpy(user_, b_.p, n_); }  // (behind the stream's synchronisation)
 };
 #define HOSTBUF_OK(x) do { if (!(x).ok()) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer"); } while (0)
+
+// A synchronous call that leaves early (a failed launch, a failed copy) may have copies in flight on the caller's buffers or on a bounce
+// buffer that is about to be freed: declared BEHIND the HostSrc / HostDst objects, so it runs before they go, it waits for the handle's
+// streams unless the call has done so itself (disarm()).
+struct DrainOnExit {
+    msiren_ctx* h;
+    bool armed = true;
+    explicit DrainOnExit(msiren_ctx* hh) : h(hh) {}
+    void disarm() { armed = false; }
+    ~DrainOnExit();
+};
 
 // the f16x3 domain guard's flag in host memory: raised by a conditional exact-fp32 trunk launch that had to run
 bool take_range_flag(msiren_ctx* h) {
@@ -1742,6 +1543,12 @@ int sync_all(msiren_ctx* h) {
         if (c.s) HIPCHK(hipStreamSynchronize(c.s));
     (void)take_range_flag(h);  // informational: the outputs are the exact-fp32 trunk's already
     return 0;
+}
+
+DrainOnExit::~DrainOnExit() {
+    if (!armed || !h) return;
+    for (auto& c : h->sc)
+        if (c.s) (void)hipStreamSynchronize(c.s);
 }
 
 // Host-pointer (synchronous) calls.  (Until round 3 a call whose f16x3 trunk raised the domain flag was run again on the
@@ -1922,36 +1729,13 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
     h->O = cfg->outer_patch_size;
     h->I = cfg->inner_patch_size;
     h->num_cus = prop.multiProcessorCount;
-    h->cus_limit = h->num_cus;
-    if (const char* e = std::getenv("MSIREN_GRID")) h->cus_limit = std::max(1, std::min(h->num_cus, std::atoi(e)));
-    if (const char* e = std::getenv("MSIREN_F16_RING")) h->ring_force = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_F16_HALF")) h->half_allowed = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_HOST_REGISTER")) h->host_register = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_ZC_OUT")) h->zc_out = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_ZC_IN")) h->zc_in = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_RECON_ZC")) h->recon_zc = std::atoi(e) & 3;
     if (const char* e = std::getenv("MSIREN_HOST_PIPE_MIN")) h->host_pipe_min = std::max(128, std::atoi(e));
-    if (const char* e = std::getenv("MSIREN_HOST_FIRST")) h->host_first = std::max(16, std::atoi(e));
-    if (const char* e = std::getenv("MSIREN_HOST_PIECE")) h->host_piece = std::max(64, std::atoi(e));
-    if (const char* e = std::getenv("MSIREN_HOST_CHUNKS")) h->host_chunks = std::max(1, std::min(std::atoi(e), 16));
     if (const char* e = std::getenv("MSIREN_QUEUE_START")) h->queue_start = (unsigned)std::strtoul(e, nullptr, 0);
     if (const char* e = std::getenv("MSIREN_F16_WS")) h->f16_ws = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_X1_WS")) h->x1_ws = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_X1_BALANCE")) h->x1_balance = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_X1_GRID")) h->x1_grid = std::atoi(e);
-    if (const char* e = std::getenv("MSIREN_RANGE_RERUN")) h->cond_rerun = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_TILING_FUSED")) h->tiling_fused = std::max(0, std::min(2, std::atoi(e)));
-    if (const char* e = std::getenv("MSIREN_HOST_CHECK")) h->host_check = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_SPLIT_MIN")) h->split_min = std::max<long long>(0, std::atoll(e));
-    if (const char* e = std::getenv("MSIREN_LINEAR_TILE_MIN")) { h->lin_tile_min = std::max(0, std::atoi(e)); h->lin_tile_env = true; }
-    if (const char* e = std::getenv("MSIREN_SPLIT_PCT")) h->split_pct = std::max(1, std::min(90, std::atoi(e)));
     if (const char* e = std::getenv("MSIREN_TRACE_HOST")) h->trace_host = std::atoi(e);
     if (const char* e = std::getenv("MSIREN_PROLOGUE_F16X3")) h->em_enabled = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_EM_PREFETCH")) h->em_prefetch = std::atoi(e) != 0;
     if (const char* e = std::getenv("MSIREN_EM_DEPTH")) h->em_depth = std::atoi(e);
-    if (const char* e = std::getenv("MSIREN_CONV_MFMA")) h->em_conv_mfma = std::atoi(e) != 0;
-    if (const char* e = std::getenv("MSIREN_WS_TWO")) h->ws_two = std::atoi(e);
-    if (const char* e = std::getenv("MSIREN_HOST_SPLIT")) h->host_first_pct = std::max(5, std::min(95, std::atoi(e)));
     declare_expected(h);
     hipError_t e = hipSetDevice(cfg->device);
     for (auto& c : h->sc)
@@ -1962,8 +1746,6 @@ int msiren_create(const msiren_config* cfg, msiren_handle* out) {
         e = hipHostGetDevicePointer((void**)&h->status_dev, (void*)h->status_host, 0);
     }
 
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->seam_host, 2 * 32 * 32 * sizeof(float), hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->seam_dev, (void*)h->seam_host, 0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) {
@@ -1981,7 +1763,6 @@ int msiren_destroy(msiren_handle h) {
         if (c.s) (void)hipStreamSynchronize(c.s);
     if (h->comm) (void)msiren_comm_destroy(h);
     if (h->status_host) (void)hipHostFree((void*)h->status_host);
-    if (h->seam_host) (void)hipHostFree((void*)h->seam_host);
     if (h->ws_comm.p) (void)hipFree(h->ws_comm.p);
     if (h->d_wp16n) (void)hipFree(h->d_wp16n);
     if (h->d_emw) (void)hipFree(h->d_emw);
@@ -1993,17 +1774,15 @@ int msiren_destroy(msiren_handle h) {
         if (p) (void)hipFree(p);
     std::vector<DevBuf*> bufs = {&h->ws_out, &h->ws_tiles, &h->ws_in, &h->ws_img};
     for (auto& c : h->sc)
-        for (DevBuf* b : {&c.cscratch, &c.mods2, &c.mods, &c.modpad, &c.latent, &c.patches, &c.keep, &c.rec, &c.queue, &c.feat, &c.plan}) bufs.push_back(b);
+        for (DevBuf* b : {&c.cscratch, &c.mods, &c.modpad, &c.latent, &c.patches, &c.keep, &c.rec, &c.queue, &c.feat, &c.plan}) bufs.push_back(b);
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& pr : h->prof_events) {
         (void)hipEventDestroy(pr.a);
         (void)hipEventDestroy(pr.b);
     }
-    for (auto& c : h->sc) {
-        if (c.ev_fork) (void)hipEventDestroy(c.ev_fork);
+    for (auto& c : h->sc)
         if (c.ev_join) (void)hipEventDestroy(c.ev_join);
-    }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (auto& c : h->sc)
@@ -2207,84 +1986,41 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     if (B == 0) return 0;
     const size_t nt = (size_t)B * h->O * h->O * sizeof(float), no = (size_t)B * h->P * sizeof(float);
     if ((rc = ensure(h, h->ws_tiles, nt)) || (rc = ensure(h, h->ws_out, no))) return rc;
-    // The call pipelines itself (round 5).  The device side of a slice is ~325 us; uploading its 1.6 MB first and downloading
-    // its 0.9 MB afterwards added ~90 us in front and behind.  Patches are independent (modulated_siren.py:435-457), so the
-    // batch is cut into chunks that alternate between the handle's two streams:
+    // From host_pipe_min tiles (2400 = six slices) up the call pipelines itself (round 5).  The device side of a slice is ~325 us; uploading
+    // its 1.6 MB first and downloading its 0.9 MB afterwards added ~90 us in front and behind.  Patches are independent
+    // (modulated_siren.py:435-457), so the batch is cut into chunks that alternate between the handle's two streams:
     //     H2D_0 | launch_0 | H2D_1 | launch_1 | D2H_0 | H2D_2 | launch_2 | D2H_1 | ... | D2H_last
     // (a pageable copy blocks the host until it is done -- so each is issued where the device has other work queued).
     // Chunk 0 is SMALL (112 tiles = two rounds of the register-resident trunk): its upload is short, so the device starts early,
-    // and its trunk runs while the next chunk's tiles arrive and its encoder / Modulator run beside it.  From 2400 tiles (six slices)
-    // up: 8 slices per call 2.57 -> 2.27 ms with staged copies; below, ONE chunk whose kernels read / write the caller's buffers in
-    // place (page-locked for the call's duration) is faster: 800 tiles 658 against 818 us, 1600 tiles 1220 against 1227, 3200 tiles
-    // 2353 against 2284 -- profiles/r5/04_host_call_pipelining.txt.  Every chunk but the
-    // last takes the register-resident trunk (room beside it for the next chunk's prologue), the last one the weight-stationary
-    // trunk (the faster kernel; nothing is left to run beside it but the previous chunk's download).  All trunk and prologue
-    // instances give the same bits, so the cut does not change results (tests/test_gpu_split.py).
-    // MSIREN_HOST_CHUNKS=1: one chunk on one stream (rounds 3-4); =2 with MSIREN_HOST_SPLIT: the even two-chunk cut of round 2.
+    // and its trunk runs while the next chunk's tiles arrive and its encoder / Modulator run beside it: 8 slices per call 2.57 -> 2.27 ms.
+    // Every chunk but the last takes the register-resident trunk (room beside it for the next chunk's prologue), the last one the
+    // weight-stationary trunk (the faster kernel; nothing is left to run beside it but the previous chunk's download).  Below the
+    // threshold ONE chunk whose kernels read / write page-locked caller buffers in place is faster: 800 tiles 658 against 818 us,
+    // 1600 tiles 1220 against 1227, 3200 tiles 2353 against 2284 (profiles/r5/04_host_call_pipelining.txt).  All trunk and prologue
+    // instances give the same bits, so the cut does not change results (tests/test_gpu_host_calls.py).
     using Chunk = msiren::HostChunk;
     std::vector<Chunk> plan;
     const int cur0 = h->cur;
-    const bool pipelined = h->host_chunks == 0 && B >= h->host_pipe_min && use_f16x3(h) && !h->x1_ready && h->L == 5 && h->em_enc && h->em_mod && ws_capable(h, B);
-    if (pipelined) {
-        plan = msiren::pipelined_host_plan(B, h->host_first, h->host_piece, cur0);  // (host_plan.h: unit-tested on the CPU)
-    } else {
-        int nchunks = std::max(1, h->host_chunks);
-        nchunks = (int)std::min<int64_t>(nchunks, B);
-        auto bound = [&](int k) -> int64_t {  // equal parts, except that two chunks may be cut unevenly (host_first_pct)
-            if (nchunks == 2 && k == 1) return std::max<int64_t>(1, std::min<int64_t>(B - 1, B * h->host_first_pct / 100));
-            return B * k / nchunks;
-        };
-        for (int k = 0; k < nchunks; ++k) plan.push_back({bound(k), bound(k + 1) - bound(k), nchunks > 1 ? (k & 1) : cur0, 0, false});
-    }
+    const bool pipelined = B >= h->host_pipe_min && use_f16x3(h) && !h->x1_ready && h->L == 5 && h->em_enc && h->em_mod && ws_capable(h, B);
+    if (pipelined) plan = msiren::pipelined_host_plan(B, h->host_first, h->host_piece, cur0);  // (host_plan.h: unit-tested on the CPU)
+    else plan.push_back({0, B, cur0, 0, false});
     const int nchunks = (int)plan.size();
     const size_t tile_elems = (size_t)h->O * h->O;
     // In place (round 5): where the caller's OUTPUT array is page-locked memory (msiren_host_alloc; the Python mirror's outputs come from a
     // recycling pool of such blocks by default; a pinned torch tensor) the trunk stores its 0.9 MB per slice straight into it over the course
-    // of its 265 us -- no download, no wait for one behind the stream.  The caller's TILES are read in place by the conv kernel: page-locked
-    // memory as it is, pageable memory (a numpy array) through a registration of the whole pages inside it for the call's duration, the
-    // first / last tile that reaches into a page shared with a neighbour through the handle's own scratch (HostLock, EncoderParams::seam).
-    // One-chunk calls only: same box, 400 tiles: 390 us with both copies, 369 with the output in place, 360 with the tiles in place as well;
-    // a cut call of 3 200 tiles: 2.24 ms with copies (they run beside the other chunk's kernels anyway), 2.35-2.87 ms in place
-    // (tools/host_zero_copy_ab.py, profiles/r5/04_host_call_pipelining.txt).
-    HostLock reg_out, reg_in;  // (released when the call returns: behind sync_all)
-    // (cut calls ask too: a buffer inside a neighbour's registration keeps that registration alive under this call's copies)
-    void* view_out = reg_out.device_view(out_host, no);
-    const bool may_lock = h->host_register && h->zc_in && B >= 64 && nchunks == 1 && h->em_enc && use_f16x3(h);
-    HostView vin = may_lock ? reg_in.interior_view(tiles_host, nt, 64 * 1024) : HostView{reg_in.device_view(tiles_host, nt), 0, nt};
-    if (!vin.dev) vin = HostView{};
-    // A buffer that is page-locked in part (another thread's call on an overlapping window of the same array; a caller's own partial
-    // hipHostRegister) goes through a page-locked bounce buffer of this call's own: rare, slow (an allocation and a CPU copy), correct.
-    HostBounce bounce_out, bounce_in;
-    float* const out_user = out_host;
-    if (reg_out.partial()) {
-        if (!bounce_out.alloc(no)) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer of %zu bytes", no);
-        out_host = (float*)bounce_out.p;
-        view_out = host_pinned_dev(out_host);
-    }
-    if (reg_in.partial()) {
-        if (!bounce_in.alloc(nt)) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer of %zu bytes", nt);
-        std::memcpy(bounce_in.p, tiles_host, nt);
-        tiles_host = (const float*)bounce_in.p;
-        vin = HostView{host_pinned_dev(tiles_host), 0, nt};
-    }
-    float* out_zc_ = h->zc_out && nchunks == 1 ? (float*)view_out : nullptr;
-    const float* in_zc_ = h->zc_in && nchunks == 1 ? (const float*)vin.dev : nullptr;
-    // the tiles that are not wholly inside the view's valid bytes: at most the first and the last one (a tile is as large as a page)
-    const size_t tile_bytes = tile_elems * sizeof(float);
-    const msiren::SeamTiles st = msiren::seam_tiles(vin.lo, vin.hi, tile_bytes, B);  // (host_plan.h)
-    const int64_t head = in_zc_ ? st.head : 0, tail_from = in_zc_ ? st.tail_from : B;
-    if (in_zc_ && (!st.ok || !h->seam_host)) in_zc_ = nullptr;  // (not this shape: copies)
-    if (in_zc_ && (head || tail_from < B)) {
-        if (head) std::memcpy(h->seam_host, tiles_host, tile_bytes);
-        if (tail_from < B) std::memcpy(h->seam_host + tile_elems, tiles_host + (size_t)tail_from * tile_elems, tile_bytes);
-        h->enc.seam = h->seam_dev;
-        h->enc.seam_head = (int)head;
-        h->enc.seam_tail = (int)tail_from;
-    }
-    struct SeamOff {  // (the handle's encoder parameters go back to "every tile where the pointer says")
-        msiren_ctx* h;
-        ~SeamOff() { h->enc.seam = nullptr; h->enc.seam_head = 0; h->enc.seam_tail = 0x7fffffff; }
-    } seam_off{h};
+    // of its 265 us -- no download, no wait for one behind the stream; page-locked TILES are read in place by the conv kernel.  Pageable
+    // memory (a plain numpy array) is copied by the runtime.  One-chunk calls only: same box, 400 tiles: 390 us with both copies, 369 with
+    // the output in place, 360 with the tiles in place as well; a cut call of 3 200 tiles: 2.24 ms with copies (they run beside the other
+    // chunk's kernels anyway), 2.35-2.87 ms in place (profiles/r5/04_host_call_pipelining.txt).
+    const HostSrc src(tiles_host, nt);  // (a range that is page-locked in part goes through a bounce buffer: host_range_kind)
+    const HostDst dst(out_host, no);
+    HOSTBUF_OK(src);
+    HOSTBUF_OK(dst);
+    DrainOnExit drain(h);  // (an early return waits for what is in flight on these buffers before they go)
+    tiles_host = src.as<float>();
+    out_host = dst.as<float>();
+    float* out_zc_ = nchunks == 1 ? dst.dev<float>() : nullptr;
+    const float* in_zc_ = nchunks == 1 ? src.dev<float>() : nullptr;
     float* const out_zc = out_zc_;
     const float* const in_zc = in_zc_;
     float* const out_base = out_zc ? out_zc : (float*)h->ws_out.p;
@@ -2292,15 +2028,13 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
     const auto t0 = clk::now();
     auto us = [&]() { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
     std::vector<double> tr_h2d(nchunks, 0.0), tr_launch(nchunks, 0.0), tr_d2h(nchunks, 0.0);
-    h->overlap = !pipelined && nchunks > 1;
-    SoloCall solo(h, nchunks == 1 || pipelined);
+    SoloCall solo(h);
     struct Restore {  // the launchers address the stream through h->cur, the trunk through h->trunk_force, the prologue's ring through h->em_beside
         msiren_ctx* h;
         int cur;
-        ~Restore() { h->cur = cur; h->trunk_force = 0; h->em_beside = false; h->overlap = false; h->no_split = false; h->trunk_after = nullptr; h->host_check_now = false; h->hc.armed = false; }
+        ~Restore() { h->cur = cur; h->trunk_force = 0; h->em_beside = false; h->trunk_after = nullptr; h->host_check_now = false; h->hc.armed = false; }
     } restore{h, cur0};
-    h->no_split = pipelined;
-    h->host_check_now = h->host_check && nchunks == 1 && !use_split(h, B);
+    h->host_check_now = nchunks == 1;
     auto download = [&](int k) {
         const Chunk& c = plan[k];
         tr_d2h[k] = us();
@@ -2348,7 +2082,8 @@ static int msiren_forward_tiles_impl(msiren_handle h, const float* tiles_host, i
         h->cur = cur0;
         rs = sync_all(h);
     }
-    if (bounce_out.p && !rc && !rs) std::memcpy(out_user, bounce_out.p, no);
+    if (!rs) drain.disarm();
+    if (!rc && !rs) dst.finish();
     if (h->trace_host) {
         std::fprintf(stderr, "msiren_forward_tiles B=%lld chunks=%d%s (us since entry): ", (long long)B, nchunks, pipelined ? " pipelined" : "");
         for (int k = 0; k < nchunks; ++k) std::fprintf(stderr, "[%lld tiles: h2d %.0f launched %.0f d2h %.0f] ", (long long)plan[k].n, tr_h2d[k], tr_launch[k], tr_d2h[k]);
@@ -2473,9 +2208,8 @@ static int reconstruct_tiles_on_current_stream(msiren_handle h, const float* ima
     // Round 5, synchronous host calls: tiling + flags + plan as ONE launch and the pass counter's reset inside the fold: 10 stream operations
     // per slice -> 7.  The host enqueues into an idle stream there, so every launch saved is ~3 us (370 against 379 us per slice, 263 against
     // 272 masked); back-to-back asynchronous calls run from a full queue and lose 0.6-1.5 % to the fused kernel's 400 device-wide fences, so
-    // they keep the separate kernels (profiles/r5/13_*).  Same bits either way (the flag is summed in the same order); MSIREN_TILING_FUSED=0 / 2:
-    // never / always.
-    const bool fused = (h->tiling_fused == 2 || (h->tiling_fused == 1 && h->solo)) && (images_dev || patches_rw);
+    // they keep the separate kernels (profiles/r5/13_*).  Same bits either way (the flag is summed in the same order).
+    const bool fused = h->solo && (images_dev || patches_rw);
     if (fused) {
         if ((rc = ensure_queue(h))) return rc;
         msiren::TilingPlanParams tp{images_dev, patches_rw, black, plan, (unsigned*)h->sc[h->cur].queue.p + 32, (int)n, height, width, nV, nH, h->O, h->I, pad, (int)NP, (h->P + 31) / 32};
@@ -2549,35 +2283,22 @@ static int msiren_reconstruct_slices_impl(msiren_handle h, const float* images_h
     const size_t ni = (size_t)n * height * width * sizeof(float);
     const size_t nr = (size_t)n * nV * h->I * nH * h->I * sizeof(float);
     if ((rc = ensure(h, h->ws_in, ni)) || (rc = ensure(h, h->ws_img, nr))) return rc;
-    // Round 5, as in msiren_forward_tiles: where the caller's reconstruction array is page-locked memory (the Python mirror's outputs are, by
-    // default) the fold stores straight into it (recon_zc & 1); a page-locked image is read in place by image_to_patches (& 2: every pixel
-    // crosses the link four times -- 32 x 32 tiles at a stride of 16 -- so off by default) or fetched by an asynchronous DMA copy.
-    // Pageable buffers are copied by the runtime: nothing of the caller's is registered here (HostLock: why).  tools/host_reconstruct_ab.py.
+    // As in msiren_forward_tiles: where the caller's reconstruction array is page-locked memory (the Python mirror's outputs are, by default)
+    // the fold stores straight into it; the image always arrives by a copy (DMA from page-locked memory, through the runtime from pageable
+    // memory): read in place every pixel would cross the link four times (32 x 32 tiles at a stride of 16; profiles/r5/09_*).
     auto& sc = h->sc[h->cur];
-    const int zc = h->recon_zc;
-    HostLock reg_out, reg_in;
-    HostBounce bounce_out, bounce_in;
-    void* view_out = reg_out.device_view(recon_host, nr);
-    void* view_in = reg_in.device_view(images_host, ni);
-    float* const recon_user = recon_host;
-    if (reg_out.partial()) {
-        if (!bounce_out.alloc(nr)) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer of %zu bytes", nr);
-        recon_host = (float*)bounce_out.p;
-        view_out = host_pinned_dev(recon_host);
-    }
-    if (reg_in.partial()) {
-        if (!bounce_in.alloc(ni)) return fail(MSIREN_E_HIP, "no page-locked memory for a bounce buffer of %zu bytes", ni);
-        std::memcpy(bounce_in.p, images_host, ni);
-        images_host = (const float*)bounce_in.p;
-        view_in = host_pinned_dev(images_host);
-    }
-    const float* d_img = (zc & 2) && view_in ? (const float*)view_in : (const float*)h->ws_in.p;
-    float* const d_rec = (zc & 1) && view_out ? (float*)view_out : (float*)h->ws_img.p;
-    if (d_img == (const float*)h->ws_in.p) HIPCHK(hipMemcpyAsync(h->ws_in.p, images_host, ni, hipMemcpyHostToDevice, sc.s));
-    if ((rc = reconstruct_on_current_stream(h, d_img, n, height, width, d_rec))) return rc;
-    if (d_rec == (float*)h->ws_img.p) HIPCHK(hipMemcpyAsync(recon_host, h->ws_img.p, nr, hipMemcpyDeviceToHost, sc.s));
+    const HostSrc src(images_host, ni);
+    const HostDst dst(recon_host, nr);
+    HOSTBUF_OK(src);
+    HOSTBUF_OK(dst);
+    DrainOnExit drain(h);
+    float* const d_rec = dst.dev<float>() ? dst.dev<float>() : (float*)h->ws_img.p;
+    HIPCHK(hipMemcpyAsync(h->ws_in.p, src.as<float>(), ni, hipMemcpyHostToDevice, sc.s));
+    if ((rc = reconstruct_on_current_stream(h, (const float*)h->ws_in.p, n, height, width, d_rec))) return rc;
+    if (d_rec == (float*)h->ws_img.p) HIPCHK(hipMemcpyAsync(dst.as<float>(), h->ws_img.p, nr, hipMemcpyDeviceToHost, sc.s));
     HIPCHK(hipStreamSynchronize(sc.s));
-    if (bounce_out.p) std::memcpy(recon_user, bounce_out.p, nr);
+    drain.disarm();
+    dst.finish();
     return 0;
 }
 
@@ -2750,6 +2471,32 @@ int msiren_device_info(msiren_handle h, char* name256, int32_t* cus, int32_t* mh
     return 0;
 }
 
+int msiren_runtime_info(int32_t* runtime_version, int32_t* built_against, int32_t* driver_version, char* lib_path, size_t lib_path_bytes) {
+    // Which HIP runtime this process's libmsiren calls end up in.  The library's only HIP dependency is NEEDED libamdhip64.so.7; a
+    // PyTorch-ROCm wheel ships its own libamdhip64.so under the SAME soname (torch/lib, ROCm 7.0 in this image), so in a process that
+    // imported torch first the dynamic loader resolves every hip* call of this library to torch's copy and its libhsa-runtime64 -- not
+    // to /opt/rocm's.  dladdr on a HIP entry point names the file that is really mapped.
+    int rv = 0, dv = 0;
+    if (hipRuntimeGetVersion(&rv) != hipSuccess) { (void)hipGetLastError(); rv = 0; }
+    if (hipDriverGetVersion(&dv) != hipSuccess) { (void)hipGetLastError(); dv = 0; }
+    if (runtime_version) *runtime_version = rv;
+    if (built_against) *built_against = HIP_VERSION;
+    if (driver_version) *driver_version = dv;
+    if (lib_path && lib_path_bytes) {
+        Dl_info di{};
+        const char* name = (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) ? di.dli_fname : "";
+        std::snprintf(lib_path, lib_path_bytes, "%s", name);
+    }
+    return 0;
+}
+
+int msiren_host_range_kind(const void* host_ptr, size_t bytes, int32_t* kind) {
+    if (!kind) return fail(MSIREN_E_INVALID, "null argument");
+    void* dev = nullptr;
+    *kind = (int32_t)host_range_kind(host_ptr, bytes, &dev);
+    return 0;
+}
+
 int msiren_device_pci(msiren_handle h, char* busid32) {
     int rc = check(h, false);
     if (rc) return rc;
@@ -2833,7 +2580,7 @@ int msiren_f16x3w_timeline(msiren_handle h, const float* mods_dev, int64_t B, fl
     while ((1 << lg) < upp) ++lg;
     p.div_k = 30 + lg;
     p.div_m = (unsigned)(((1ULL << p.div_k) + (unsigned)upp - 1) / (unsigned)upp);
-    const int grid = (int)std::min<int64_t>(h->cus_limit, ((int64_t)p.total_units + 1) / 2);
+    const int grid = (int)std::min<int64_t>(h->num_cus, ((int64_t)p.total_units + 1) / 2);
     DevBuf st, q;
     struct Free {  // whichever way the function is left
         DevBuf &a, &b;

@@ -64,6 +64,5 @@ extern template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 3>(EmTailParam
 extern template __global__ void latent_mods_f16x3_kernel<4, 1, 8, 3>(EmTailParams);
 extern template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 1>(EmTailParams);
 extern template __global__ void latent_mods_f16x3_kernel<4, 1, 4, 2>(EmTailParams);
-extern template __global__ void encoder_conv_f16x3_kernel<0>(EncoderParams, const float*, em_u4*, float*);
 extern template __global__ void encoder_conv_f16x3_kernel<1>(EncoderParams, const float*, em_u4*, float*);
 }  // namespace msiren

@@ -99,10 +99,24 @@ class _PinnedPool:
     """Recycles page-locked blocks by size (hipHostMalloc costs ~100 us; the blocks of a steady loop are reused).  At most
     `keep` idle blocks per size are kept; the rest is freed.  `cap_bytes` bounds what is handed out at one time when the caller
     did not ask for page-locked memory explicitly (the default outputs of the host-pointer calls): beyond it array() returns
-    None and the caller falls back to ordinary memory -- an application that keeps thousands of outputs alive does not pin them all."""
+    None and the caller falls back to ordinary memory -- an application that keeps thousands of outputs alive does not pin them all.
 
-    def __init__(self, model, keep=8, cap_bytes=512 << 20):
-        self._model, self._free, self._keep, self._cap, self._out = model, {}, keep, cap_bytes, 0
+    The pool does NOT reference its model (blocks reference the pool, the model references the pool: a back reference would be a
+    cycle, and `del model` would free the GPU handle only at the next gc pass -- while any result array was alive, never).  It
+    holds the library and a one-element cell with the model's handle, which the model empties when it destroys the handle.  Blocks
+    are freed through msiren_host_free(NULL, ptr): nothing of a handle is touched from whatever thread the last array dies on."""
+
+    def __init__(self, keep=8, cap_bytes=512 << 20):
+        self._lib, self._cell = None, [None]          # set by attach()
+        self._free, self._keep, self._cap, self._out = {}, keep, cap_bytes, 0
+
+    def attach(self, lib, handle):
+        self._lib, self._cell[0] = lib, handle
+
+    def detach(self):
+        """The handle is about to be destroyed: idle blocks go, blocks under live arrays stay valid and free themselves later."""
+        self.drain()
+        self._cell[0] = None
 
     def array(self, shape, strict=True):
         shape = tuple(int(x) for x in shape)
@@ -113,8 +127,12 @@ class _PinnedPool:
         if lst:
             ptr = lst.pop()
         else:
+            if self._cell[0] is None:
+                if strict:
+                    raise _lib.MsirenError("the model has no device handle (destroyed or never created)")
+                return None
             p = C.c_void_p()
-            rc = self._model._lib.msiren_host_alloc(self._model._h, nbytes, C.byref(p))
+            rc = self._lib.msiren_host_alloc(self._cell[0], nbytes, C.byref(p))
             if rc != 0 and not strict:
                 return None
             _lib.check(rc)
@@ -125,17 +143,15 @@ class _PinnedPool:
     def _give_back(self, ptr, nbytes):
         self._out -= nbytes
         lst = self._free.setdefault(nbytes, [])
-        if len(lst) < self._keep and self._model._h:
+        if len(lst) < self._keep and self._cell[0] is not None:
             lst.append(ptr)
-        elif self._model._lib is not None:   # (also for a block whose array has outlived the handle: freed without one)
-            self._model._lib.msiren_host_free(self._model._h, ptr)
+        elif self._lib is not None:
+            self._lib.msiren_host_free(None, ptr)
 
     def drain(self):
         for lst in self._free.values():
             while lst:
-                ptr = lst.pop()
-                if self._model._h:
-                    self._model._lib.msiren_host_free(self._model._h, ptr)
+                self._lib.msiren_host_free(None, lst.pop())
 
 
 class ModulatedSiren:
@@ -173,7 +189,7 @@ class ModulatedSiren:
                                       "scope of the MI355X path; use encoder_type='custom'")
         self._lib = None
         self._h = None
-        self._pinned = _PinnedPool(self)   # page-locked host arrays (pinned_empty, pin_outputs)
+        self._pinned = _PinnedPool()       # page-locked host arrays (pinned_empty, pin_outputs)
         self._pin_outputs = True           # outputs of the host-pointer calls come from the pool (the kernels store into them in place)
         self._device = _device_index(device)
         self._committed = False
@@ -241,6 +257,7 @@ class ModulatedSiren:
         cfg = self._config()
         _lib.check(self._lib.msiren_create(C.byref(cfg), C.byref(h)))
         self._h = h
+        self._pinned.attach(self._lib, h)
         self._committed = False
 
     def _push_tensors(self):
@@ -358,9 +375,7 @@ class ModulatedSiren:
         if idx is None:
             raise _lib.MsirenError("ModulatedSiren (MI355X build) has no CPU path; .to('cpu') is not supported")
         if idx != self._device and self._h is not None:
-            self._pinned.drain()
-            self._lib.msiren_destroy(self._h)
-            self._h = None
+            self._destroy_handle()
         self._device = idx
         self._ensure_committed()
         return self
@@ -382,12 +397,15 @@ class ModulatedSiren:
     def parameters(self):
         return [v for k, v in self._sd.items() if k != "grid"]
 
+    def _destroy_handle(self):
+        if self._h is not None and self._lib is not None:
+            self._pinned.detach()   # (blocks still under a live array stay allocated: their arrays outlive the handle)
+            self._lib.msiren_destroy(self._h)
+            self._h = None
+
     def __del__(self):
         try:
-            if self._h is not None and self._lib is not None:
-                self._pinned.drain()   # (blocks still under a live array stay allocated: their arrays outlive the model)
-                self._lib.msiren_destroy(self._h)
-                self._h = None
+            self._destroy_handle()
         except Exception:
             pass
 

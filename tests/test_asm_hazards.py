@@ -385,7 +385,7 @@ def test_no_vector_memory_instruction_of_the_built_library_reads_a_freshly_valu_
             assert not bad, name + "\n" + "\n".join(bad[:8])
             vm_total += seen
     assert lds_total > 2000 and vm_total > 2000, (lds_total, vm_total)
-    assert sum("latent_mods_f16x3_kernel" in nm for nm in names) >= 8 and sum("encoder_conv_f16x3_kernel" in nm for nm in names) == 2
+    assert sum("latent_mods_f16x3_kernel" in nm for nm in names) >= 8 and sum("encoder_conv_f16x3_kernel" in nm for nm in names) == 1
     assert sum("siren_trunk_x1w_kernel" in nm for nm in names) == 8 and total > 5000, (len(names), total)
 
 

@@ -82,3 +82,38 @@ def test_product_never_imports_oracle():
     for path in extra:
         src = open(path).read()
         assert "from oracle" not in src and "import oracle" not in src, path
+
+
+def test_runtime_info_names_the_hip_runtime_the_library_is_bound_to():
+    """msiren_runtime_info (no handle, no device needed): the library links libamdhip64.so.7 by soname and a PyTorch-ROCm wheel bundles a
+    libamdhip64.so of the same soname -- in a process that imported torch first every HIP call of libmsiren runs on torch's bundled
+    runtime, in a torch-free process on the system one.  Both orders in child processes: the reported path is the file that is mapped
+    (/proc/self/maps), there is exactly one libamdhip64 in the process, and the two orders really do end up on different files here."""
+    import json
+    import subprocess
+    import sys
+
+    prog = ("import sys, json\n"
+            "if sys.argv[1] == 'torch':\n    import torch\n"
+            "from mri_inr_amd import _lib\n"
+            "info = _lib.runtime_info()\n"
+            "mapped = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+            "print(json.dumps({'info': info, 'mapped': mapped}))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ("plain", "torch"):
+        r = subprocess.run([sys.executable, "-c", prog, mode], cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+        info, mapped = got[mode]["info"], got[mode]["mapped"]
+        assert len(mapped) == 1, mapped                                         # one HIP runtime per process
+        assert os.path.realpath(info["libamdhip64"]) == os.path.realpath(mapped[0]), (info, mapped)
+        assert info["hip_runtime_version"] and info["built_against_hip"]
+    assert got["plain"]["info"]["torch_bundled"] is False
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        return
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):   # a ROCm wheel: the torch-first process is on the bundled runtime
+        assert got["torch"]["info"]["torch_bundled"] is True and os.path.realpath(got["torch"]["info"]["libamdhip64"]) == os.path.realpath(tl)

@@ -1,10 +1,9 @@
-"""Large asynchronous calls overlap with themselves (mri_inr_amd/csrc/msiren.hip: forward_tiles_split), and the paths the
-benchmark's timed region runs are checked against the reference's fixtures DIRECTLY (not through another path's output).
-
-With MSIREN_SPLIT_MIN=3200 (round 4's default; off since round 5: with the one-launch prologue the uncut call is as fast or faster,
-profiles/r5/07_*) a call of >= 3200 tiles on a one-stream handle is cut in two: the encoder + Modulator of most of the batch run on the handle's other stream
-beside the register-resident trunk of the first part, the weight-stationary trunk of the rest follows.  Patches are
-independent (modulated_siren.py:435-457) and the two trunks give the same bits, so nothing may change.
+"""Host-pointer calls, the paths the benchmark's timed region runs, and the same-bits properties between code paths that all ship:
+one chunk in place / the pipelined cut of several slices; the host-side domain check of synchronous calls / the conditional launch of
+asynchronous ones; the fused tiling kernel of synchronous slice calls / the separate kernels of asynchronous ones; the 16 x 16 / the
+32 x 32-tile Linear kernels of the exact-fp32 prologue.  Round 6: the paths that had lost their A/Bs (the cut of one large *_dev call,
+MSIREN_SPLIT_MIN; per-call page-locking; the knobs that selected losers) are gone from the library, and so are their tests; every
+comparison here is between two paths the library takes by itself.
 """
 import os
 
@@ -14,90 +13,13 @@ import pytest
 from conftest import load_golden
 from mri_inr_amd import _lib, synthetic as syn
 from oracle import siren_oracle as orc
-from test_gpu_parity import check, make_model
+from test_gpu_parity import check, make_model, make_with_env
 
 pytestmark = pytest.mark.gpu
 
 
-def make_with_env(sd, env, **kw):
-    """The knobs are read once, at msiren_create."""
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
-    try:
-        return make_model(sd, **kw)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
 def run_dev(m, d_in, n, d_out):
     _lib.check(m._lib.msiren_forward_tiles_dev(m._h, d_in.ptr, n, d_out.ptr))
-
-
-@pytest.mark.parametrize("act", ["sine", "morlet"])
-def test_split_call_same_bits_as_uncut_call(act):
-    sd = syn.make_state_dict(seed=7, trained_like=True)
-    B = 3300
-    tiles = np.random.default_rng(11).random((B, 32, 32), dtype=np.float32)
-    whole = make_with_env(sd, {"MSIREN_SPLIT_MIN": 0}, act=act, precision="f16x3")
-    d_in, d_out = whole.device_array(tiles.shape).copy_from(tiles), whole.device_array((B, 24, 24))
-    run_dev(whole, d_in, B, d_out)
-    whole.sync()
-    ref = d_out.numpy()
-    assert whole.last_trunk_kernel().startswith("siren_trunk_f16x3w_kernel")
-    check(ref[:32], orc.modulated_siren_forward(sd, tiles[:32], num_layers=5, activation=act, dtype=np.float64))
-    check(ref[-32:], orc.modulated_siren_forward(sd, tiles[-32:], num_layers=5, activation=act, dtype=np.float64))
-    a = 1 if act == "morlet" else 0
-    for env in ({"MSIREN_SPLIT_MIN": 3200}, {"MSIREN_SPLIT_MIN": 3200, "MSIREN_SPLIT_PCT": 30}, {"MSIREN_SPLIT_MIN": 3200, "MSIREN_SPLIT_PCT": 1}, {"MSIREN_SPLIT_MIN": 3300}):
-        m = make_with_env(sd, env, act=act, precision="f16x3")
-        d_i, d_o = m.device_array(tiles.shape).copy_from(tiles), [m.device_array((B, 24, 24)) for _ in range(2)]
-        for streams in (1, 2):
-            _lib.check(m._lib.msiren_set_streams(m._h, streams))
-            _lib.check(m._lib.msiren_profile_enable(m._h, 1))
-            for k in range(4):   # back to back: the second part's modulations cross streams, call after call
-                run_dev(m, d_i, B, d_o[k & 1])
-            m.sync()
-            ks = {k["kernel"]: k for k in m.profile_kernels()}
-            _lib.check(m._lib.msiren_profile_enable(m._h, 0))
-            assert sum(k["coords"] for k in ks.values()) == 4 * B * 576 and all(k["launches"] == 4 for k in ks.values())
-            if streams == 1:   # the call overlaps with itself
-                assert set(ks) == {f"siren_trunk_f16x3n_kernel<{a},3,5>", f"siren_trunk_f16x3w_kernel<{a},4>"}, ks
-                assert ks[f"siren_trunk_f16x3w_kernel<{a},4>"]["coords"] > ks[f"siren_trunk_f16x3n_kernel<{a},3,5>"]["coords"]
-            else:              # two streams: consecutive calls overlap with each other, nothing is cut
-                assert set(ks) == {f"siren_trunk_f16x3n_kernel<{a},3,5>"}, ks
-            for o in d_o:
-                assert np.array_equal(o.numpy(), ref), (env, streams)
-        # the synchronous host call goes the same way
-        assert np.array_equal(m(tiles), ref)
-        # below the threshold nothing is cut
-        _lib.check(m._lib.msiren_set_streams(m._h, 1))
-        run_dev(m, d_i, 3100, d_o[0])
-        m.sync()
-        assert m.last_trunk_kernel() == f"siren_trunk_f16x3w_kernel<{a},4>"
-        assert np.array_equal(d_o[0].numpy()[:3100], ref[:3100])
-
-
-def test_split_is_not_taken_where_it_does_not_apply():
-    """(with MSIREN_SPLIT_MIN=3200) Other depths, the exact-fp32 trunk and the masked slice pipeline (tile count known to the device only) run uncut."""
-    tiles = np.random.default_rng(12).random((3300, 32, 32), dtype=np.float32)
-    for L, prec in ((4, "f16x3"), (5, "fp32")):
-        sd = syn.make_state_dict(seed=3, num_layers=L, trained_like=True)
-        m = make_with_env(sd, {"MSIREN_SPLIT_MIN": 3200}, L=L, precision=prec)
-        _lib.check(m._lib.msiren_profile_enable(m._h, 1))
-        out = m(tiles)
-        assert len(m.profile_kernels()) == 1
-        check(out[:16], orc.modulated_siren_forward(sd, tiles[:16], num_layers=L, dtype=np.float64))
-    sd = syn.make_state_dict(seed=7, trained_like=True)
-    m = make_with_env(sd, {"MSIREN_SPLIT_MIN": 3200})
-    imgs = np.stack([syn.make_slice(k, brain_mask=True) for k in range(9)])
-    _lib.check(m._lib.msiren_profile_enable(m._h, 1))
-    rec = m.reconstruct(imgs)
-    assert len(m.profile_kernels()) == 1
-    assert np.array_equal(rec[8], m.reconstruct(imgs[8]))
-
 
 @pytest.mark.parametrize("act", ["sine", "morlet"])
 def test_two_stream_headline_path_vs_reference_fixture(act):
@@ -125,7 +47,6 @@ def test_two_stream_headline_path_vs_reference_fixture(act):
         for r in (0, 17, 49):
             check(got[r], g["out"])
 
-
 def test_full_slice_reconstruct_vs_fp64_oracle():
     """One full 320x320 masked slice through the device pipeline (tiles -> black filter -> forward -> weighted fold)
     against the oracle's float64 reconstruction (tiling.py:10-140,244-303 + modulated_siren.py:435-457)."""
@@ -143,47 +64,50 @@ def test_full_slice_reconstruct_vs_fp64_oracle():
     for o in d_rec:
         assert np.array_equal(o.numpy()[0], rec)
 
-
 @pytest.mark.parametrize("H,Z,L,B", [(256, 256, 5, 1100), (256, 256, 5, 1037), (64, 48, 3, 1030), (48, 16, 2, 1025), (512, 128, 10, 1056), (512, 128, 3, 300)])
 def test_tiled_linear_layers_same_bits_as_the_16x16_kernel(H, Z, L, B):
-    """Throughput sizes run conv3, Linear(64, Z) and the Modulator layers on 32 x 32 output tiles
-    (linear_mfma_tile_kernel<2, 2>), latency sizes on 16 x 16: same MFMA chains, same K split, same reduction order --
-    `self.modulator(self.encoder(tiles))` (modulated_siren.py:446) must not depend on the batch a tile came in."""
+    """Exact-fp32 handles: throughput sizes (>= 1024 rows; >= 256 for layers of >= 512 outputs) run conv3, Linear(64, Z) and the
+    Modulator layers on 32 x 32 output tiles (linear_mfma_tile_kernel<2, 2>), latency sizes on 16 x 16: same MFMA chains, same K split,
+    same reduction order -- `self.modulator(self.encoder(tiles))` (modulated_siren.py:446) must not depend on the batch a tile came in.
+    The whole batch (tiled kernel) against the same rows in pieces below the threshold (16 x 16 kernel), in one handle."""
     kw = dict(dim_hidden=H, num_layers=L, latent_dim=Z)
     sd = syn.make_state_dict(seed=21, trained_like=True, **kw) if H != 512 else \
         syn.make_state_dict(seed=21, modulator_bias_center=0.25, encoder_gain=10.0, **kw)
-    mk = dict(H=H, L=L, Z=Z, precision="fp32")
-    small = make_with_env(sd, {"MSIREN_LINEAR_TILE_MIN": 0}, **mk)
-    tiled = make_with_env(sd, {"MSIREN_LINEAR_TILE_MIN": 1}, **mk)
-    auto = make_model(sd, **mk)   # default threshold: 1024 rows (256 for layers of >= 512 outputs)
+    m = make_model(sd, H=H, L=L, Z=Z, precision="fp32")
     tiles = np.random.default_rng(B).random((B, 32, 32), dtype=np.float32)
-    z = small.encoder(tiles)
-    assert np.array_equal(tiled.encoder(tiles), z) and np.array_equal(auto.encoder(tiles), z)
-    assert np.array_equal(auto.encoder(tiles[:70]), z[:70])          # (16 x 16 kernel in the same handle)
+    z = m.encoder(tiles)                                              # tiled kernels
+    step = 200                                                        # below every threshold
+    z_small = np.concatenate([m.encoder(tiles[lo:lo + step]) for lo in range(0, B, step)])
+    assert np.array_equal(z_small, z)
     check(z[:40], orc.encoder_forward(sd, tiles[:40], dtype=np.float64), tol=1e-5)
-    mods = small.modulator(z)
-    for a, b, c in zip(mods, tiled.modulator(z), auto.modulator(z)):
-        assert np.array_equal(a, b) and np.array_equal(a, c)
+    mods = m.modulator(z)
+    for l, a in enumerate(mods):
+        small = np.concatenate([m.modulator(z[lo:lo + step])[l] for lo in range(0, B, step)])
+        assert np.array_equal(a, small), l
     ref = orc.modulator_forward(sd, z[:40].astype(np.float64), num_layers=L, dtype=np.float64)
     for a, r in zip(mods, ref):
         check(a[:40], r, tol=1e-5)
-    # the masked slice pipeline hands the row count over on the device
+    # the masked slice pipeline hands the row count over on the device: five slices at once (tiled) against one by one (16 x 16)
     if H == 256:
         imgs = np.stack([syn.make_slice(k, brain_mask=True) for k in range(5)])
-        assert np.array_equal(small.reconstruct(imgs), tiled.reconstruct(imgs))
-
+        rec = m.reconstruct(imgs)
+        for k in range(5):
+            assert np.array_equal(m.reconstruct(imgs[k]), rec[k]), k
 
 def test_host_call_of_several_slices_pipelines_itself_same_bits():
-    """A numpy -> numpy call of >= MSIREN_HOST_PIPE_MIN tiles (default 2400; 800 / 128 here) cuts itself into chunks over the handle's two streams (uploads and downloads beside the
-    other chunk's kernels; msiren_forward_tiles_impl).  Patches are independent and every trunk / prologue instance gives the same
-    bits, so nothing may change -- also with asynchronous *_dev work still pending on the helper stream of a two-stream handle."""
+    """A numpy -> numpy call of >= MSIREN_HOST_PIPE_MIN tiles (default 2400; 800 / 128 here) cuts itself into chunks over the handle's two
+    streams (uploads and downloads beside the other chunk's kernels; msiren_forward_tiles_impl, host_plan.h).  Patches are independent and
+    every trunk / prologue instance gives the same bits, so nothing may change against the one-chunk call (the default below the threshold)
+    -- also with asynchronous *_dev work still pending on the helper stream of a two-stream handle."""
     sd = syn.make_state_dict(seed=7, trained_like=True)
     B = 1339
     tiles = np.random.default_rng(17).random((B, 32, 32), dtype=np.float32)
-    one = make_with_env(sd, {"MSIREN_HOST_CHUNKS": 1, "MSIREN_SPLIT_MIN": 0}, precision="f16x3")
+    one = make_model(sd, precision="f16x3")               # 1339 < 2400: one chunk
+    _lib.check(one._lib.msiren_profile_enable(one._h, 1))
     ref = one(tiles)
+    assert [k["kernel"] for k in one.profile_kernels()] == ["siren_trunk_f16x3w_kernel<0,4>"]
     check(ref[:24], orc.modulated_siren_forward(sd, tiles[:24], num_layers=5, dtype=np.float64))
-    for env in ({"MSIREN_HOST_PIPE_MIN": 800}, {"MSIREN_HOST_PIPE_MIN": 800, "MSIREN_HOST_FIRST": 56, "MSIREN_HOST_PIECE": 200}, {"MSIREN_HOST_PIPE_MIN": 128, "MSIREN_HOST_FIRST": 40}):
+    for env in ({"MSIREN_HOST_PIPE_MIN": 800}, {"MSIREN_HOST_PIPE_MIN": 128}):
         m = make_with_env(sd, env, precision="f16x3")
         _lib.check(m._lib.msiren_profile_enable(m._h, 1))
         assert np.array_equal(m(tiles), ref), env
@@ -203,42 +127,19 @@ def test_host_call_of_several_slices_pipelines_itself_same_bits():
             assert np.array_equal(o.numpy(), ref[:400])
         _lib.check(m._lib.msiren_set_streams(m._h, 1))
 
-
-def test_out_of_domain_modulation_in_the_second_part_of_a_cut_call():
-    """With MSIREN_SPLIT_MIN=3200 a >= 3200-tile call on a one-stream handle is cut in two (forward_tiles_split); a tile whose modulations leave the fp16
-    domain lies in the SECOND part: that part's launch is repaired by the conditional exact-fp32 trunk (which reads mods2 with
-    p.B = B1), the first part keeps its split-fp16 bits."""
-    sd = syn.make_state_dict(seed=7, trained_like=True)
-    B = 3300
-    tiles = np.random.default_rng(23).random((B, 32, 32), dtype=np.float32)
-    m = make_with_env(sd, {"MSIREN_SPLIT_MIN": 3200}, precision="f16x3")
-    clean = m(tiles)
-    bad = tiles.copy()
-    bad[3000] *= 3e7          # latent ~1e7 -> modulations far beyond 65504
-    z = m.encoder(bad)
-    mods = np.stack(m.modulator(z), 0)
-    assert np.abs(mods[:, 3000]).max() > 1e5 and np.isfinite(mods).all()
-    B0 = (B * 12 // 100 + 15) // 16 * 16                      # forward_tiles_split's first part (MSIREN_SPLIT_PCT = 12)
-    d_in, d_out = m.device_array(bad.shape).copy_from(bad), m.device_array((B, 24, 24))
-    _lib.check(m._lib.msiren_profile_enable(m._h, 1))
-    run_dev(m, d_in, B, d_out)
-    m.sync()
-    assert len(m.profile_kernels()) == 2                       # the call was cut
-    got = d_out.numpy()
-    exact = make_model(sd, precision="fp32")
-    assert np.array_equal(got[:B0], clean[:B0])                                  # first part: untouched
-    assert np.array_equal(got[B0:], exact.forward_mods(mods[:, B0:]))            # second part: the exact-fp32 trunk's bits
-    assert np.isfinite(got).all()
-
-
 def test_page_locked_buffers_same_bits_recycled_and_outlive_the_model():
-    """msiren_host_alloc / model.pinned_empty / model.pin_outputs: with page-locked input and output the copies are asynchronous DMA
-    without staging (one slice: 437 -> 394 us).  Same bits as the pageable call, at every size and through the cut call of
-    several slices; the pool recycles blocks; arrays stay valid after their model is gone."""
+    """msiren_host_alloc / model.pinned_empty / model.pin_outputs: with page-locked input and output the kernels work on the caller's
+    arrays in place.  Same bits as the pageable call, at every size and through the cut call of several slices; the pool recycles blocks.
+    Arrays outlive their model: `del model` destroys the GPU handle AT ONCE (the pool holds no reference to the model: no cycle, no wait
+    for a gc pass), the arrays stay readable, and their blocks are freed later through msiren_host_free(NULL, ptr)."""
+    import ctypes
+    import gc
+    import weakref
+
     sd = syn.make_state_dict(seed=7, trained_like=True)
     tiles = np.random.default_rng(31).random((400, 32, 32), dtype=np.float32)
     m = make_with_env(sd, {"MSIREN_HOST_PIPE_MIN": 800}, precision="f16x3")
-    ref = m(tiles)                                   # pageable in, pageable out: one chunk
+    ref = m(tiles)                                   # pageable in, pool block out: one chunk
     _lib.check(m._lib.msiren_profile_enable(m._h, 1))
     m(tiles)
     assert len(m.profile_kernels()) == 1
@@ -264,15 +165,28 @@ def test_page_locked_buffers_same_bits_recycled_and_outlive_the_model():
     assert again.ctypes.data == ptr0 or np.array_equal(again, ref)   # (the block came back from the pool)
     m.pin_outputs(False)
     keep = m(pin).copy()
-    del m
-    import gc
-    gc.collect()
+    # the model goes, by reference count alone
+    lib, cell, pool = m._lib, m._pinned._cell, weakref.ref(m._pinned)
+    gc.disable()
+    try:
+        wm = weakref.ref(m)
+        del m
+        assert wm() is None and cell[0] is None      # __del__ has run: handle destroyed, the pool's handle cell emptied
+    finally:
+        gc.enable()
+    k = ctypes.c_int32(-1)
+    _lib.check(lib.msiren_host_range_kind(ctypes.c_void_p(again.ctypes.data), ctypes.c_size_t(again.nbytes), ctypes.byref(k)))
+    assert k.value == 1                              # the block is still page-locked memory under the live array ...
     assert np.array_equal(again, ref) and np.array_equal(keep, ref) and np.array_equal(pin, tiles)
+    addr, nbytes = again.ctypes.data, again.nbytes
+    del again, pin                                   # ... and goes through msiren_host_free(NULL, ptr) when the last array does
+    gc.collect()
+    assert pool() is None
+    _lib.check(lib.msiren_host_range_kind(ctypes.c_void_p(addr), ctypes.c_size_t(nbytes), ctypes.byref(k)))
+    assert k.value == 0
 
-
-def test_by_default_a_large_call_on_a_one_stream_handle_is_one_trunk_launch():
-    """Round 5: MSIREN_SPLIT_MIN defaults to 0 -- behind the one-launch prologue the uncut call is as fast at 64 slices and faster at 8
-    (profiles/r5/07_*)."""
+def test_a_large_call_on_a_one_stream_handle_is_one_trunk_launch():
+    """Behind the one-launch prologue the uncut call is as fast at 64 slices and faster at 8 (profiles/r5/07_*): round 6 deleted the cut."""
     sd = syn.make_state_dict(seed=7, trained_like=True)
     m = make_model(sd, precision="f16x3")
     tiles = np.random.default_rng(3).random((3300, 32, 32), dtype=np.float32)
@@ -282,31 +196,31 @@ def test_by_default_a_large_call_on_a_one_stream_handle_is_one_trunk_launch():
     m.sync()
     ks = m.profile_kernels()
     assert len(ks) == 1 and ks[0]["kernel"] == "siren_trunk_f16x3w_kernel<0,4>" and ks[0]["coords"] == 3300 * 576, ks
-    cut = make_with_env(sd, {"MSIREN_SPLIT_MIN": 3200}, precision="f16x3")
-    assert np.array_equal(d_out.numpy(), cut(tiles))
-
+    got = d_out.numpy()
+    check(got[:32], orc.modulated_siren_forward(sd, tiles[:32], num_layers=5, dtype=np.float64))
+    check(got[-32:], orc.modulated_siren_forward(sd, tiles[-32:], num_layers=5, dtype=np.float64))
+    assert np.array_equal(m(tiles), got)                       # the host call of 3300 tiles pipelines itself: same bits
 
 def test_host_slice_call_in_place_same_bits_as_staged_copies():
-    """msiren_reconstruct_slices (numpy slice -> numpy reconstruction, the reference's metrics_error pattern): since round 5 the caller's
-    buffers are page-locked for the call, the fold stores into the caller's array and the image arrives by DMA from the locked pages
-    (MSIREN_RECON_ZC=5; 0 = staged copies, 3 = both buffers in place).  Same bits in every mode -- masked slices, several slices per call,
-    sizes that are not a multiple of the stride, buffers that are page-locked in part by the caller."""
+    """msiren_reconstruct_slices (numpy slice -> numpy reconstruction, the reference's metrics_error pattern): where the caller's
+    reconstruction array is page-locked memory (the mirror's pool, its default) the fold stores into it; with pin_outputs(False) the
+    reconstruction is downloaded.  Same bits -- masked slices, several slices per call, sizes that are not a multiple of the stride,
+    buffers that are page-locked in part by the caller."""
     import ctypes
 
     sd = syn.make_state_dict(seed=7, trained_like=True)
     imgs = np.stack([syn.make_slice(k, 320, 320, brain_mask=bool(k & 1)) for k in range(3)])
     odd = syn.make_slice(5, 200, 170)
-    staged = make_with_env(sd, {"MSIREN_RECON_ZC": 0}, precision="f16x3")
-    ref, ref_odd = staged.reconstruct(imgs), staged.reconstruct(odd)
+    m = make_model(sd, precision="f16x3")
+    m.pin_outputs(False)
+    ref, ref_odd = m.reconstruct(imgs), m.reconstruct(odd)          # staged copies
     assert ref.shape == (3, 320, 320) and ref_odd.shape == (208, 176) and np.isfinite(ref).all()
-    for zc in (5, 1, 3, 4):
-        m = make_with_env(sd, {"MSIREN_RECON_ZC": zc}, precision="f16x3")
-        assert np.array_equal(m.reconstruct(imgs), ref), zc
-        assert np.array_equal(m.reconstruct(imgs[1]), ref[1]), zc
-        assert np.array_equal(m.reconstruct(odd), ref_odd), zc
+    m.pin_outputs(True)
+    assert np.array_equal(m.reconstruct(imgs), ref)
+    assert np.array_equal(m.reconstruct(imgs[1]), ref[1])
+    assert np.array_equal(m.reconstruct(odd), ref_odd)
     # the caller page-locks the first slice of a stack and calls on slices 0..1 and 1..2: the first range is page-locked in part
     hip = ctypes.CDLL("libamdhip64.so")
-    m = make_model(sd, precision="f16x3")
     stack = imgs.copy()
     assert hip.hipHostRegister(ctypes.c_void_p(stack.ctypes.data), ctypes.c_size_t(320 * 320 * 4), ctypes.c_uint(0)) == 0
     try:
@@ -315,7 +229,6 @@ def test_host_slice_call_in_place_same_bits_as_staged_copies():
         assert np.array_equal(m.reconstruct(stack[0]), ref[0])
     finally:
         assert hip.hipHostUnregister(ctypes.c_void_p(stack.ctypes.data)) == 0
-
 
 def test_back_to_back_one_stream_calls_across_the_edge_of_the_fp16_domain():
     """One-stream handle, msiren_forward_tiles_dev calls back to back without a sync; out-of-domain batches and clean ones alternate, other entry
@@ -361,23 +274,29 @@ def test_back_to_back_one_stream_calls_across_the_edge_of_the_fp16_domain():
     m.sync()
     assert np.array_equal(outs[0].numpy(), want["bad"])
 
-
 def test_synchronous_host_call_checks_the_domain_flag_on_the_host():
-    """A one-chunk msiren_forward_tiles call waits for its stream anyway: since round 5 its trunk raises the out-of-domain flag in host memory and
-    the call looks at it after the wait -- no conditional launch per call; a flagged call runs the exact-fp32 trunk then (and downloads again
-    where it copies).  Same buffers as with the conditional launch (MSIREN_HOST_CHECK=0): in place (400 tiles), with copies (48 tiles), on
-    page-locked arrays; clean calls before and after a flagged one keep their split-fp16 bits; the event counter counts."""
+    """A one-chunk msiren_forward_tiles call waits for its stream anyway: its trunk raises the out-of-domain flag in host memory and the
+    call looks at it after the wait -- no conditional launch per call; a flagged call runs the exact-fp32 trunk then (and downloads again
+    where it copies).  Same buffers as the asynchronous API gives with its conditional launch: in place (400 tiles), with copies
+    (48 tiles), on page-locked arrays; clean calls before and after a flagged one keep their split-fp16 bits; the event counter counts."""
     sd = syn.make_state_dict(seed=7, trained_like=True)
     rng = np.random.default_rng(33)
     clean = rng.random((400, 32, 32), dtype=np.float32)
     bad = clean.copy()
     bad[37] *= 3e7
     exact = make_model(sd, precision="fp32")
-    old = make_with_env(sd, {"MSIREN_HOST_CHECK": 0}, precision="f16x3")
-    mods_of = lambda x: np.stack(old.modulator(old.encoder(x)), 0)
-    want_clean, want_bad, want_bad48 = old(clean), exact.forward_mods(mods_of(bad)), exact.forward_mods(mods_of(bad[:48]))
-    assert np.array_equal(old(bad), want_bad) and np.array_equal(old(bad[:48]), want_bad48)
     m = make_model(sd, precision="f16x3")
+
+    def via_dev(x):      # the asynchronous entry point: conditional launch on the stream
+        d_i, d_o = m.device_array(x.shape).copy_from(x), m.device_array((x.shape[0], 24, 24))
+        run_dev(m, d_i, x.shape[0], d_o)
+        m.sync()
+        return d_o.numpy()
+
+    mods_of = lambda x: np.stack(m.modulator(m.encoder(x)), 0)
+    want_clean, want_bad, want_bad48 = via_dev(clean), exact.forward_mods(mods_of(bad)), exact.forward_mods(mods_of(bad[:48]))
+    assert np.array_equal(via_dev(bad), want_bad) and np.array_equal(via_dev(bad[:48]), want_bad48)
+
     def events(mm):
         import ctypes as C
 
@@ -389,13 +308,13 @@ def test_synchronous_host_call_checks_the_domain_flag_on_the_host():
     assert np.array_equal(m(clean), want_clean) and events(m) == e0
     assert np.array_equal(m(bad), want_bad) and events(m) == e0 + 1            # in place
     assert np.array_equal(m(clean), want_clean) and events(m) == e0 + 1
+    m.pin_outputs(False)
     assert np.array_equal(m(bad[:48]), want_bad48) and events(m) == e0 + 2     # copies: downloaded again
     assert np.array_equal(m(clean[:48]), want_clean[:48])
+    m.pin_outputs(True)
     pin = m.pinned_empty(bad.shape)
     pin[...] = bad
-    m.pin_outputs(True)
     assert np.array_equal(m(pin), want_bad) and events(m) == e0 + 3
-    m.pin_outputs(False)
     # asynchronous calls keep the conditional launch; a host call right behind one
     d_in, d_out = m.device_array(bad.shape).copy_from(bad), m.device_array((400, 24, 24))
     run_dev(m, d_in, 400, d_out)
@@ -403,30 +322,38 @@ def test_synchronous_host_call_checks_the_domain_flag_on_the_host():
     m.sync()
     assert np.array_equal(d_out.numpy(), want_bad)
 
-
 def test_fused_tiling_flags_plan_same_bits_as_the_separate_kernels():
-    """Round 5: image_to_patches + black_flags + compact_flags as one launch (the workgroup that draws the last ticket builds the plan) and the
-    pass counter's reset inside the fold.  MSIREN_TILING_FUSED=0 = the separate kernels: the same reconstruction bit for bit -- masked and
-    unmasked slices, several per call, odd sizes, all-black and no-black inputs, many calls in a row (the ticket counter is put back each time),
-    one and two streams."""
+    """Synchronous host calls (msiren_reconstruct_slices) run image_to_patches + black_flags + compact_flags as ONE launch (the workgroup
+    that draws the last ticket builds the plan) with the pass counter's reset inside the fold; asynchronous calls
+    (msiren_reconstruct_slices_dev) keep the separate kernels (profiles/r5/13_*).  The same reconstruction bit for bit -- masked and
+    unmasked slices, several per call, odd sizes, all-black and no-black inputs, many calls in a row (the ticket counter is put back each
+    time), one to three streams, forward calls in between (they share the pass counter the fold resets)."""
     sd = syn.make_state_dict(seed=7, trained_like=True)
     imgs = np.stack([syn.make_slice(k, 320, 320, brain_mask=bool(k % 3)) for k in range(6)])
     odd = syn.make_slice(9, 200, 170, brain_mask=True)
     black = np.zeros((320, 320), np.float32)
-    sep = make_with_env(sd, {"MSIREN_TILING_FUSED": 0}, precision="f16x3")
-    m = make_with_env(sd, {"MSIREN_TILING_FUSED": 2}, precision="f16x3")      # (2: on the asynchronous API as well; the default fuses in host calls only)
-    want, want_odd = sep.reconstruct(imgs), sep.reconstruct(odd)
-    assert np.array_equal(make_model(sd, precision="f16x3").reconstruct(imgs), want)
-    assert np.array_equal(sep.reconstruct(black), np.zeros_like(black))
+    m = make_model(sd, precision="f16x3")
+
+    def sep(x):          # the asynchronous entry point: separate kernels
+        x3 = x if x.ndim == 3 else x[None]
+        n, hh, ww = x3.shape
+        d_i = m.device_array(x3.shape).copy_from(x3)
+        d_r = m.device_array((n, (hh + 15) // 16 * 16, (ww + 15) // 16 * 16))
+        _lib.check(m._lib.msiren_reconstruct_slices_dev(m._h, d_i.ptr, n, hh, ww, d_r.ptr))
+        m.sync()
+        r = d_r.numpy()
+        return r if x.ndim == 3 else r[0]
+
+    want, want_odd = sep(imgs), sep(odd)
+    assert np.array_equal(sep(black), np.zeros_like(black))
     for rep in range(3):
-        assert np.array_equal(m.reconstruct(imgs), want)
+        assert np.array_equal(m.reconstruct(imgs), want)                 # fused
         assert np.array_equal(m.reconstruct(odd), want_odd)
         assert np.array_equal(m.reconstruct(black), np.zeros_like(black))
         for k in range(6):
             assert np.array_equal(m.reconstruct(imgs[k]), want[k]), k
-    # asynchronous calls back to back on one and two streams, forward calls in between (they share the pass counter the fold resets)
     tiles = np.random.default_rng(41).random((100, 32, 32), dtype=np.float32)
-    want_t = sep(tiles)
+    want_t = m(tiles)
     d_i = m.device_array(imgs.shape).copy_from(imgs)
     d_t, d_to = m.device_array(tiles.shape).copy_from(tiles), [m.device_array((100, 24, 24)) for _ in range(4)]
     for streams in (1, 2, 3):
@@ -436,6 +363,8 @@ def test_fused_tiling_flags_plan_same_bits_as_the_separate_kernels():
             _lib.check(m._lib.msiren_reconstruct_slices_dev(m._h, d_i.ptr + (j % 6) * 320 * 320 * 4, 1, 320, 320, d_r[j].ptr))
             if j % 3 == 1:
                 run_dev(m, d_t, 100, d_to[j // 3])
+            if j == 7:
+                assert np.array_equal(m.reconstruct(imgs[2]), want[2])   # a fused synchronous call in the middle of the queue
         m.sync()
         for j in range(12):
             assert np.array_equal(d_r[j].numpy()[0], want[j % 6]), (streams, j)

@@ -31,6 +31,20 @@ def make_model(sd, *, H=256, L=5, Z=256, S=24, act="sine", use_bias=True, **kw):
     return m
 
 
+def make_with_env(sd, env, **kw):
+    """make_model under environment knobs: they are read once, at msiren_create."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return make_model(sd, **kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def check(out, ref, tol=TOL, rtol=RMS_TOL):
     assert out.shape == ref.shape, (out.shape, ref.shape)
     assert out.dtype == np.float32
@@ -824,9 +838,10 @@ def test_two_handles_from_two_threads():
 
 
 def test_two_threads_share_one_pageable_input_array():
-    """Round 5: a one-chunk host call page-locks its pageable buffers for its duration and lets the kernels read / write them in place.  Two
-    handles in two threads that are handed THE SAME input array (and slices of it) share one reference-counted registration: the call that
-    returns first must not unlock the pages under the other's kernels.  Every output equals the single-threaded one; nothing faults."""
+    """Two handles in two threads are handed THE SAME pageable input array (and slices of it that lie inside the other thread's range).
+    Inputs are only read: the library leaves the caller's memory as it is (no registration, no page-locking -- include/msiren.h), each call
+    copies its tiles through the runtime, the outputs are blocks of each model's own page-locked pool written in place.  Every output
+    equals the single-threaded one."""
     import threading
 
     sd = syn.make_state_dict(seed=7, trained_like=True)
@@ -853,10 +868,16 @@ def test_two_threads_share_one_pageable_input_array():
     for th in threads:
         th.join(timeout=300)
     assert not errors, errors[:5]
-    # without the per-call page-locking (MSIREN_HOST_REGISTER=0: staged copies) the same bits
-    from test_gpu_split import make_with_env
-    plain = make_with_env(sd, {"MSIREN_HOST_REGISTER": 0}, precision="f16x3")
-    assert np.array_equal(plain(shared), ref)
+    assert _range_kind(models[0], shared) == 0          # still ordinary pageable memory: nothing of the caller's was page-locked
+
+
+def _range_kind(m, a):
+    """msiren_host_range_kind of a numpy array's bytes: 0 pageable, 1 inside one page-locked allocation, 2 page-locked in part."""
+    import ctypes
+
+    k = ctypes.c_int32(-1)
+    _lib.check(m._lib.msiren_host_range_kind(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes), ctypes.byref(k)))
+    return k.value
 
 
 def _forward_into(m, x, out):
@@ -869,9 +890,8 @@ def _forward_into(m, x, out):
 
 def test_windows_of_one_array_from_two_threads():
     """The parallel-for over slices: two handles in two threads work on WINDOWS of one input array and one output array -- adjacent ones
-    (disjoint bytes that share a page at the seam) and input windows that overlap in part.  A window that is page-locked in part by the
-    neighbour's call gets neither a device view nor a runtime copy (hipMemcpy refuses a range that leaves a registration): it goes through
-    a bounce buffer (HostLock::partial).  Every output equals the single-threaded one; no call fails; nothing faults."""
+    (disjoint bytes that share a page at the seam) and input windows that overlap in part.  All of it pageable memory that the library only
+    copies from / to.  Every output equals the single-threaded one; no call fails."""
     import threading
 
     sd = syn.make_state_dict(seed=7, trained_like=True)
@@ -911,8 +931,12 @@ def test_windows_of_one_array_from_two_threads():
 
 def test_buffers_page_locked_in_part_go_through_a_bounce_buffer():
     """Deterministic form of the above: the CALLER page-locks rows [0, 300) of an input and of an output array (hipHostRegister), then calls on
-    rows [200, 600): the first byte of either buffer is page-locked, the last is not.  Same bits as on untouched arrays; fully page-locked
-    and fully pageable windows of the same arrays work as ever."""
+    rows [200, 600): the first byte of either buffer is page-locked, the last is not (msiren_host_range_kind: 2).  Neither a kernel nor a
+    runtime copy is safe on such a range (hipMemcpy refuses a range that leaves the registration it begins in): it goes through a bounce
+    buffer.  Same bits as on untouched arrays; fully page-locked and fully pageable windows of the same arrays work as ever.  Then the
+    case both of whose ENDS are page-locked while the middle is not (two registrations, pageable rows in between): the device address of
+    page-locked memory equals its host address here, so the ends alone prove nothing -- the allocation that holds the first byte must
+    hold the last (hipMemGetAddressRange); a kernel let loose on that range would fault on the pageable rows."""
     import ctypes
 
     hip = ctypes.CDLL("libamdhip64.so")
@@ -924,6 +948,11 @@ def test_buffers_page_locked_in_part_go_through_a_bounce_buffer():
     assert hip.hipHostRegister(ctypes.c_void_p(x.ctypes.data), ctypes.c_size_t(300 * 32 * 32 * 4), ctypes.c_uint(0)) == 0
     assert hip.hipHostRegister(ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(300 * 24 * 24 * 4), ctypes.c_uint(0)) == 0
     try:
+        assert [_range_kind(m, x[a:b]) for a, b in ((200, 600), (0, 300), (50, 250), (300, 700), (0, 700))] == [2, 1, 1, 0, 2]
+        assert _range_kind(m, out[0:300]) == 1 and _range_kind(m, out[100:301]) == 2 and _range_kind(m, out[300:]) == 0
+        pool_block = m.pinned_empty((64, 32, 32))
+        assert _range_kind(m, pool_block) == 1 and _range_kind(m, pool_block[3:40]) == 1       # (what the in-place default path rests on)
+        del pool_block
         for lo, hi in ((200, 600), (0, 300), (300, 700), (250, 314), (0, 700)):
             out[:] = 0
             _forward_into(m, x[lo:hi], out[lo:hi])
@@ -948,6 +977,18 @@ def test_buffers_page_locked_in_part_go_through_a_bounce_buffer():
     out[:] = 0
     _forward_into(m, x[200:600], out[200:600])
     assert np.array_equal(out[200:600], ref[200:600])
+    # two registrations with pageable rows between them: rows [0, 100) and [200, 300) page-locked, the call on rows [50, 250)
+    row = 32 * 32 * 4
+    for lo in (0, 200):
+        assert hip.hipHostRegister(ctypes.c_void_p(x.ctypes.data + lo * row), ctypes.c_size_t(100 * row), ctypes.c_uint(0)) == 0
+    try:
+        assert _range_kind(m, x[50:250]) == 2 and _range_kind(m, x[0:100]) == 1 and _range_kind(m, x[200:300]) == 1 and _range_kind(m, x[100:200]) == 0
+        o3 = m.pinned_empty((200, 24, 24))
+        _forward_into(m, x[50:250], o3)
+        assert np.array_equal(o3, ref[50:250])
+    finally:
+        for lo in (0, 200):
+            assert hip.hipHostUnregister(ctypes.c_void_p(x.ctypes.data + lo * row)) == 0
 
 
 @pytest.mark.parametrize("start", ["0xFFFFF800", "0x7FFFF800"])

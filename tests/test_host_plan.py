@@ -48,27 +48,6 @@ PROG = textwrap.dedent(r"""
             const auto t = pipelined_host_plan(1000, 112, 400, 0);  // 88 left: absorbed by the last chunk
             assert(t.size() == 3 && t[2].n == 488);
         }
-        {   // whole pages inside a caller's range; the tiles that reach out of them (a numpy array begins 16 bytes into a page)
-            const InsidePages p = inside_pages(0x10000010, 400 * 4096);
-            assert(p.lo == 0x10001000 && p.hi == 0x10000000 + 400 * 4096);
-            const SeamTiles s = seam_tiles(p.lo - 0x10000010, p.hi - 0x10000010, 4096, 400);
-            assert(s.head == 1 && s.tail_from == 399 && s.ok);                       // tiles 0 and 399 through the scratch, 1..398 in place
-            const InsidePages q = inside_pages(0x20000000, 64 * 4096);               // page-aligned: everything in place
-            const SeamTiles r = seam_tiles(q.lo - 0x20000000, q.hi - 0x20000000, 4096, 64);
-            assert(q.lo == 0x20000000 && q.hi == 0x20000000 + 64 * 4096 && r.head == 0 && r.tail_from == 64 && r.ok);
-            const InsidePages n = inside_pages(0x30000010, 4000);                    // nothing whole inside
-            assert(n.lo >= n.hi);
-            assert(!seam_tiles(4080, 2 * 4096 - 16, 4096, 2).ok);                    // two tiles: both reach out, nothing left in between
-            assert(!seam_tiles(5000, 400 * 4096, 4096, 400).ok);                     // two head tiles: not what the scratch holds
-            for (uintptr_t off : {0u, 16u, 64u, 2048u, 4095u})
-                for (int64_t B : {3, 64, 400, 2399}) {
-                    const uintptr_t a = 0x40000000 + off;
-                    const InsidePages w = inside_pages(a, (size_t)B * 4096);
-                    const SeamTiles u = seam_tiles(w.lo - a, w.hi - a, 4096, B);
-                    assert(u.ok && u.head == (off ? 1 : 0) && u.tail_from == (off ? B - 1 : B));
-                    for (int64_t t = u.head; t < u.tail_from; ++t) assert(a + t * 4096 >= w.lo && a + (t + 1) * 4096 <= w.hi);
-                }
-        }
         // the packed weight stream: H = Z = 256, L = 5 (every shipped YAML): 32 + 8 + 80 + 64 k-steps per wave = 2.9 MB in all
         {
             const auto s = em_stream_layout(2, 2, 5, true, true);

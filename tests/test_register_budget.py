@@ -25,7 +25,6 @@ template __global__ void msiren::siren_trunk_f16x3n_kernel<0, 3, 5>(msiren::Trun
 template __global__ void msiren::siren_trunk_f16x3n_kernel<1, 3, 5>(msiren::TrunkF16Params);
 template __global__ void msiren::linear_mfma_tile_kernel<2, 2>(msiren::ModulatorMfmaParams);
 template __global__ void msiren::latent_mods_f16x3_kernel<2, 2, 2, 3>(msiren::EmTailParams);
-template __global__ void msiren::encoder_conv_f16x3_kernel<0>(msiren::EncoderParams, const float*, msiren::em_u4*, float*);
 template __global__ void msiren::encoder_conv_f16x3_kernel<1>(msiren::EncoderParams, const float*, msiren::em_u4*, float*);
 template __global__ void msiren::siren_trunk_f32_cond_kernel<0>(msiren::TrunkParams);
 template __global__ void msiren::siren_trunk_f32_cond_kernel<1>(msiren::TrunkParams);
@@ -61,7 +60,7 @@ def test_trunk_and_its_neighbours_fit_on_one_cu(tmp_path):
     assert len(trunks) == 2 and len(beside) >= 11 and any("linear_mfma_tile" in k for k in beside), list(usage)  # the register-resident 16x16x32 trunk, sine / Morlet
     # round 5: the one-launch split-fp16 prologue (ring of 2) and its conv kernels run beside the trunk as well -- and without scratch
     tail = [k for k in beside if "latent_mods_f16x3" in k]
-    assert len(tail) == 1 and sum("encoder_conv_f16x3" in k for k in beside) == 2, list(beside)
+    assert len(tail) == 1 and sum("encoder_conv_f16x3" in k for k in beside) == 1, list(beside)
     for k in beside:
         if "f16x3" in k:
             assert beside[k]["ScratchSize"] == 0, (k, beside[k])
