@@ -26,7 +26,7 @@ def make_grid(siren_patch_size: int) -> np.ndarray:
 
     Reference: src/networks/modulated_siren.py:427-433 (meshgrid indexing="ij").
     Computed the way torch.linspace does in fp32 (start + i*step for the first half,
-    end - (S-1-i)*step for the second); agrees with torch's CPU result to one ulp (torch's own
+    end - (S-1-i)*step for the second); agrees with torch's CPU result to 1.2e-7 (one ulp at 1; torch's own
     last bit depends on the host's SIMD width).  Real checkpoints carry the buffer in their state_dict.
     """
     S = int(siren_patch_size)

@@ -165,6 +165,45 @@ def write_model_variants(ModulatedSiren, FixedAutoencoder, torch):
     return sorted(store)
 
 
+def write_reference_grid(ModulatedSiren, FixedAutoencoder, torch):
+    """(2c) the reference's OWN coordinate buffer.  Every other fixture loads this build's grid into the reference with strict=True; here
+    "grid" is dropped from the state_dict and the rest loaded with strict=False, so what `ModulatedSiren.__init__` registers
+    (linspace + meshgrid(indexing="ij"), modulated_siren.py:427-433) produces the output: the buffer itself for S = 24 (every YAML),
+    10 and 16, and forward(tiles) / the trunk on seeded modulations with it at S = 24 (sine and Morlet)."""
+    from mri_inr_amd import synthetic as syn
+
+    store = {}
+    H, L, Z = 256, 5, 256
+    sd = {k: v for k, v in syn.make_state_dict(seed=7, trained_like=True).items() if k != "grid"}
+    tiles = np.random.default_rng(1).random((7, 32, 32), dtype=np.float32)
+    mods = syn.make_mods(34, L, 5, H)
+    for act in ("sine", "morlet"):
+        with tempfile.TemporaryDirectory() as td:
+            ckpt = os.path.join(td, "enc.pth")
+            torch.save({"state_dict": FixedAutoencoder().state_dict()}, ckpt)
+            model = ModulatedSiren(dim_in=2, dim_hidden=H, dim_out=1, num_layers=L, latent_dim=Z, w0=1.0, w0_initial=30.0, use_bias=True,
+                                   dropout=0.1, modulate=True, encoder_type="custom", encoder_path=ckpt, outer_patch_size=32,
+                                   inner_patch_size=16, siren_patch_size=24, device=torch.device("cpu"), activation=act)
+        res = model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=False)
+        assert list(res.missing_keys) == ["grid"] and not res.unexpected_keys, res
+        model.eval()
+        store["grid_24"] = model.grid.numpy().copy()
+        with torch.no_grad():
+            store[f"forward_{act}"] = model(torch.from_numpy(tiles)).numpy()
+        store[f"trunk_{act}"] = _run_net(model, mods)
+    for S in (10, 16):
+        with tempfile.TemporaryDirectory() as td:
+            ckpt = os.path.join(td, "enc.pth")
+            torch.save({"state_dict": FixedAutoencoder().state_dict()}, ckpt)
+            model = ModulatedSiren(dim_in=2, dim_hidden=32, dim_out=1, num_layers=2, latent_dim=16, w0=1.0, w0_initial=30.0, use_bias=True,
+                                   dropout=0.1, modulate=True, encoder_type="custom", encoder_path=ckpt, outer_patch_size=32,
+                                   inner_patch_size=16, siren_patch_size=S, device=torch.device("cpu"), activation="sine")
+        store[f"grid_{S}"] = model.grid.numpy().copy()
+    store["meta"] = np.array(json.dumps(dict(seed=7, trained_like=True, tiles_seed=1, B=7, mods_seed=34, mods_B=5, torch=torch.__version__)))
+    np.savez_compressed(os.path.join(GOLD, "reference_grid.npz"), **store)
+    return sorted(store)
+
+
 GEOMETRIES = ((8, 16), (16, 32), (32, 32), (16, 20))
 
 
@@ -274,6 +313,7 @@ def main():
 
     manifest["cases"]["tiling_geometries"] = write_tiling_geometries(rt, torch)
     manifest["cases"]["model_variants"] = write_model_variants(ModulatedSiren, FixedAutoencoder, torch)
+    manifest["cases"]["reference_grid"] = write_reference_grid(ModulatedSiren, FixedAutoencoder, torch)
 
     # ---- (4b) whole-slice reconstruction as metrics_error drives it (error.py:231-249) --------
     sdg = syn.make_state_dict(seed=7, trained_like=True)
@@ -321,7 +361,7 @@ def main():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] in (["geometries"], ["variants"]):  # add one file without regenerating the others
+    if sys.argv[1:] in (["geometries"], ["variants"], ["grid"]):  # add one file without regenerating the others
         sys.path.insert(0, REPO)
         _ms, _ae, _rt = _import_reference()
         import torch
@@ -329,6 +369,8 @@ if __name__ == "__main__":
         torch.set_num_threads(8)
         if sys.argv[1] == "geometries":
             key, keys = "tiling_geometries", write_tiling_geometries(_rt, torch)
+        elif sys.argv[1] == "grid":
+            key, keys = "reference_grid", write_reference_grid(_ms, _ae, torch)
         else:
             key, keys = "model_variants", write_model_variants(_ms, _ae, torch)
         mpath = os.path.join(GOLD, "MANIFEST.json")

@@ -28,11 +28,23 @@ import numpy as np
 # --------------------------------------------------------------------------------------------
 
 
+def linspace_f32(start: float, end: float, steps: int) -> np.ndarray:
+    """``torch.linspace(start, end, steps)`` in fp32 as ATen evaluates it (RangeFactories: ``start + i*step`` below the midpoint,
+    ``end - (steps-1-i)*step`` from it on, everything in fp32).  The oracle's OWN statement -- it does not borrow the product's helper
+    (mri_inr_amd/synthetic.py); both are pinned by the reference's own buffer in tests/golden/reference_grid.npz."""
+    f = np.float32
+    if steps == 1:
+        return np.array([start], dtype=np.float32)
+    step = f((f(end) - f(start)) / f(steps - 1))
+    i = np.arange(steps)
+    lo = (f(start) + step * i.astype(np.float32)).astype(np.float32)
+    hi = (f(end) - step * (steps - 1 - i).astype(np.float32)).astype(np.float32)
+    return np.where(i < steps // 2, lo, hi).astype(np.float32)
+
+
 def make_grid(S: int, dtype=np.float32) -> np.ndarray:
     """(S*S, 2) grid, row ``h*S+w`` = (lin[h], lin[w]).  Ref: modulated_siren.py:427-433."""
-    from mri_inr_amd.synthetic import torch_like_linspace
-
-    lin = torch_like_linspace(-1.0, 1.0, S).astype(dtype)
+    lin = linspace_f32(-1.0, 1.0, S).astype(dtype)
     g = np.empty((S, S, 2), dtype=dtype)
     g[:, :, 0] = lin[:, None]
     g[:, :, 1] = lin[None, :]

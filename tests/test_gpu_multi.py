@@ -102,17 +102,23 @@ def test_rccl_group_object_and_comm_init_all():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("act", ["sine", "morlet"])
 @pytest.mark.parametrize("prec", ["fp32", "f16x3"])
-def test_commit_without_the_grid_buffer(prec):
-    """A C-ABI consumer may omit "grid" (the reference registers it as a buffer, modulated_siren.py:427-433): the
-    library rebuilds it, for every trunk -- same bits as with the buffer supplied."""
+def test_commit_without_the_grid_buffer(prec, act):
+    """A C-ABI consumer may omit "grid" (the reference registers it as a buffer, modulated_siren.py:427-433): the library rebuilds
+    it, for every trunk.  Checked against the REFERENCE run the same way -- tests/golden/reference_grid.npz: "grid" dropped from the
+    state_dict, strict=False, so the reference's own linspace / meshgrid buffer produced the fixture -- and, with the reference's buffer
+    loaded instead, against the same fixture again; the rebuilt grid gives the bits of the build's own."""
+    from conftest import load_golden, nerr
     from mri_inr_amd import ModulatedSiren, _lib, synthetic as syn
 
+    g = load_golden("reference_grid.npz")
     sd = syn.make_state_dict(seed=7, trained_like=True)
     kw = dict(dim_in=2, dim_hidden=256, dim_out=1, num_layers=5, latent_dim=256, w0=1.0, w0_initial=30.0, use_bias=True,
               dropout=0.1, modulate=True, encoder_type="custom", encoder_path=None, outer_patch_size=32, inner_patch_size=16,
-              siren_patch_size=24, device="cuda:0", activation="sine", precision=prec)
-    tiles = np.random.default_rng(1).random((7, 32, 32), dtype=np.float32)
+              siren_patch_size=24, device="cuda:0", activation=act, precision=prec)
+    tiles = np.random.default_rng(1).random((7, 32, 32), dtype=np.float32)      # the fixture's input (oracle/gen_fixtures.py)
+    mods = syn.make_mods(34, 5, 5, 256)
     a = ModulatedSiren(**kw)
     a.load_state_dict(sd)
     want = a.to("cuda:0")(tiles)
@@ -123,7 +129,16 @@ def test_commit_without_the_grid_buffer(prec):
             _lib.check(b._lib.msiren_set_tensor(b._h, k.encode(), v.ctypes.data, v.size))
     _lib.check(b._lib.msiren_commit_weights(b._h))
     b._committed = True
-    assert np.array_equal(b(tiles), want)
+    got = b(tiles)
+    assert np.array_equal(got, want)                                            # rebuilt grid == the build's own
+    assert nerr(got, g[f"forward_{act}"]) < 1e-4                                # ... and within the gate of the reference on ITS grid
+    assert nerr(b.forward_mods(mods), g[f"trunk_{act}"].reshape(5, 24, 24)) < 1e-4
+    c = ModulatedSiren(**kw)
+    c.load_state_dict(dict(sd, grid=g["grid_24"]))                              # the reference's buffer, as a real checkpoint carries it
+    c.to("cuda:0")
+    assert np.array_equal(c.state_dict()["grid"], g["grid_24"])
+    assert nerr(c(tiles), g[f"forward_{act}"]) < 1e-4
+    assert nerr(c.forward_mods(mods), g[f"trunk_{act}"].reshape(5, 24, 24)) < 1e-4
 
 
 def _model_kwargs(**over):
@@ -265,6 +280,18 @@ def test_bench_two_ranks_rehearsal_reports_what_the_communicator_saw(tmp_path):
     assert d["n_gpus"] == 2 and d["collective_fallback"] is False
     assert d["config"]["rccl_ranks"] == 2 and d["config"]["rccl_lib"] == stub
     assert d["config"]["ranks_hold_identical_weights"] is True
+    # the line carries BOTH regions: the weak one-slice-per-rank `value` (what N = 1 reports) and, behind it in the same process group,
+    # BASELINE configs[2] strong -- 64 slices sharded 32 + 32 -- with its efficiency against the stored N = 1 figure (the scaling claim)
+    assert d["scaling"] == "weak" and d["config"]["slices_per_step_total"] == 2
+    assert abs(d["value"] - 2 * 320 * 320 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+    st = d["extra"]["configs"]["config3_64_slices_strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["slices_per_rank"] == [32, 32] and st["rccl_ranks"] == 2
+    assert abs(st["value"] - 64 * 320 * 320 / st["ms_per_step"] / 1e3) < 1e-6 * st["value"]
+    assert st["n1_reference_value"] > 0 and "n1_reference.json" in st["n1_reference_source"]
+    assert abs(st["efficiency_vs_n1"] - st["value"] / (2 * st["n1_reference_value"])) < 1e-9
+    assert 0.3 < st["efficiency_vs_n1"] < 0.75        # two ranks SHARE one card here: about half, never the claim itself
+    assert d["config"]["also_measured"]["config3_64_slices_strong"]["value"] == st["value"]
+    assert d["config"]["hip_runtime"]["torch_bundled"] is False and d["config"]["torch_first"] is False
 
 
 def _bench(args, env=None, timeout=900):
@@ -299,6 +326,13 @@ def test_bench_single_gpu_line_carries_roofline_cpu_baseline_and_extras():
     assert d["collective_fallback"] is False and d["config"]["comm_ranks"] == 1
     ex = d["extra"]
     assert 0 < ex["host_to_host_mpixel_s"] < d["value"] * 1.05   # PCIe-inclusive: never faster than device-resident
+    # SURVEY section 8(d)'s primary region and the strict-fp32 trunk as top-level keys (and inside config / roofline, which the driver keeps)
+    assert d["host_to_host"]["value"] == ex["host_to_host_mpixel_s"] and d["host_to_host"]["unit"] == "Mpixel/s"
+    assert d["config"]["also_measured"]["host_to_host_mpixel_s"] == ex["host_to_host_mpixel_s"]
+    assert d["fp32"]["kernel"] == "siren_trunk_f32_kernel<256,0,0>" and d["fp32"]["value"] == ex["configs"]["fp32_trunk"]["value"]
+    assert 0.5 < d["fp32"]["kernel_alone_frac"] < 1.0 and d["roofline"]["fp32_trunk"]["kernel_alone_frac"] == d["fp32"]["kernel_alone_frac"]
+    rt = d["config"]["hip_runtime"]
+    assert rt["torch_bundled"] is False and rt["hip_runtime_version"] == rt["built_against_hip"] and d["config"]["torch_first"] is False
     assert ex["reconstruct_mpixel_s"] > 0 and 0 < ex["host_slice_to_slice_mpixel_s"] < ex["reconstruct_mpixel_s"] * 1.05
     # every other BASELINE configuration rides in the driver-run line (child runs behind the timed region, never `value`)
     cfgs = ex["configs"]
@@ -323,6 +357,8 @@ def test_bench_gpus2_starts_its_own_ranks_gloo_rehearsal_on_one_card():
     d = _bench(["--gpus", "2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"], env)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["slices_per_step_total"] == 2
     assert abs(d["value"] - 2 * 320 * 320 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+    assert d["extra"]["configs"]["config3_64_slices_strong"]["slices_per_rank"] == [32, 32]      # the strong region rides along
+    assert d["config"]["hip_runtime"]["torch_bundled"] is True                                    # (gloo: torch came first)
     s = _bench(["--gpus", "2", "--total-slices", "6", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"], env)
     assert s["n_gpus"] == 2 and s["scaling"] == "strong"
     assert s["config"]["slices_per_step_total"] == 6 and s["config"]["slices_per_step_rank0"] == 3
@@ -341,6 +377,16 @@ def test_bench_two_rccl_ranks_on_one_card_rendezvous_then_fall_back():
     assert d["config"]["ranks_hold_identical_weights"] is True
     assert "RCCL init failed" in d["config"]["backend"]
     assert abs(d["value"] - 2 * 320 * 320 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+
+
+def test_bench_torch_first_runs_on_torchs_bundled_hip_runtime():
+    """--torch-first = the reference's own host program (torch imported before anything else): libmsiren's HIP calls resolve to torch's
+    bundled libamdhip64 (same soname).  The line names the runtime; the numbers of both orders are on file in profiles/r6/02_*."""
+    d = _bench(["--torch-first", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-extras"])
+    rt = d["config"]["hip_runtime"]
+    assert d["config"]["torch_first"] is True and rt["torch_bundled"] is True and "/torch/lib/" in rt["libamdhip64"]
+    assert rt["hip_runtime_version"] != rt["built_against_hip"]      # this image: torch bundles ROCm 7.0, the system is 7.2
+    assert d["value"] > 0 and d["roofline"]["kernel"] == "siren_trunk_f16x3n_kernel<0,3,5>"
 
 
 def test_bench_strong_scaling_config3_single_gpu():

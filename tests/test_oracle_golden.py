@@ -214,3 +214,31 @@ def test_tiling_roundtrip_property():
         assert np.abs(weighted[:hh, :ww] - img).max() < 1e-6
 
     prop()
+
+
+@pytest.mark.parametrize("act", ["sine", "morlet"])
+def test_reference_built_its_own_grid(act):
+    """tests/golden/reference_grid.npz: "grid" dropped from the state_dict, the rest loaded with strict=False, so the buffer that
+    `ModulatedSiren.__init__` registers (linspace + meshgrid(indexing="ij"), modulated_siren.py:427-433) produced the outputs.  The
+    build's grid (mri_inr_amd/synthetic.py, rebuilt in the library when a checkpoint lacks it) and the oracle's own (siren_oracle.py)
+    agree with that buffer to 1.2e-7 (one ulp at |x| = 1: torch's CPU linspace is vectorised, its last bit depends on the host's SIMD
+    width, so no restatement is bit-exact on every host -- real checkpoints carry the buffer); the outputs agree within the gate with
+    either grid."""
+    g = load_golden("reference_grid.npz")
+    for S in (24, 10, 16):
+        ref = g[f"grid_{S}"]
+        assert ref.shape == (S * S, 2) and ref.dtype == np.float32
+        assert ref[0].tolist() == [-1.0, -1.0] and ref[-1].tolist() == [1.0, 1.0] and ref[1].tolist()[0] == -1.0   # row-major over (h, w)
+        for mine in (syn.make_grid(S), orc.make_grid(S)):
+            assert np.abs(mine.astype(np.float64) - ref).max() <= 1.2e-7, S
+    sd = syn.make_state_dict(seed=7, trained_like=True)
+    tiles = np.random.default_rng(1).random((7, 32, 32), dtype=np.float32)
+    mods = syn.make_mods(34, 5, 5, 256)
+    for grid in (None, g["grid_24"]):
+        s = {k: v for k, v in sd.items() if k != "grid"}
+        if grid is not None:
+            s["grid"] = grid
+        out = orc.modulated_siren_forward(s, tiles, num_layers=5, activation=act, dtype=np.float32)
+        assert nerr(out, g[f"forward_{act}"]) < 1e-4
+        trunk = orc.siren_forward(s, mods, num_layers=5, activation=act, dtype=np.float32).reshape(5, 24, 24)
+        assert nerr(trunk, g[f"trunk_{act}"].reshape(5, 24, 24)) < 1e-4
