@@ -1,8 +1,15 @@
-// Kernel instantiations of the trunk translation units (k_*.hip), declared `extern` for msiren.hip: the host file parses the
+// Kernel instantiations of the trunk translation units (k_*.hip), declared `extern` for the host units: a host file parses the
 // kernel headers for their parameter structs, LDS layouts and schedules, but the device code of every trunk instance is
 // generated once, in its own translation unit (make -j: six compilers side by side instead of one 4-minute run).
 // GENERATED together with k_*.hip by the list in this file's history; keep the two in step (the link fails otherwise).
 #pragma once
+#include "encoder_modulator_f16x3.hip.h"
+#include "siren_trunk_f16x3h.hip.h"
+#include "siren_trunk_f16x3n.hip.h"
+#include "siren_trunk_f16x3w.hip.h"
+#include "siren_trunk_f32.hip.h"
+#include "siren_trunk_x1n.hip.h"
+#include "siren_trunk_x1w.hip.h"
 namespace msiren {
 extern template __global__ void siren_trunk_f32_kernel<128, 0, 0>(TrunkParams);
 extern template __global__ void siren_trunk_f32_kernel<128, 0, 1>(TrunkParams);
