@@ -20,14 +20,17 @@ HostKind host_range_kind(const void* host, size_t bytes, void** dev) {
     if (!d) return (bytes > 1 && host_pinned_dev((const char*)host + bytes - 1)) ? HOST_PARTIAL : HOST_PAGEABLE;
     // both ends inside page-locked memory is not enough (two allocations, pageable bytes in between; on this platform the device
     // address of page-locked memory usually EQUALS its host address, so "d_last == d + bytes - 1" proves nothing): the allocation
-    // that holds the first byte must hold the last one -- base and size of it from the runtime.
-    hipDeviceptr_t base = nullptr;
+    // that holds the first byte must hold the last one -- its start and size from the runtime.  hipPointerGetAttribute's RANGE_START_ADDR
+    // / RANGE_SIZE answer for hipHostMalloc blocks and hipHostRegister'ed ranges alike, at interior pointers too, on both runtimes a
+    // process can end up on; hipMemGetAddressRange reports base 0 for registered memory (tools/ptr_range_probe.py, profiles/r6/05_*).
+    void* start = nullptr;
     size_t size = 0;
-    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)d) != hipSuccess) {
+    if (hipPointerGetAttribute(&start, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)host) != hipSuccess ||
+        hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, (hipDeviceptr_t)host) != hipSuccess || !start) {
         (void)hipGetLastError();
         return HOST_PARTIAL;  // (the runtime cannot name the allocation: do not trust the range)
     }
-    if ((uintptr_t)d + bytes > (uintptr_t)base + size) return HOST_PARTIAL;
+    if ((uintptr_t)host < (uintptr_t)start || (uintptr_t)host + bytes > (uintptr_t)start + size) return HOST_PARTIAL;
     *dev = d;
     return HOST_PINNED;
 }

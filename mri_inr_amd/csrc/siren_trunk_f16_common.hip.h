@@ -8,7 +8,7 @@
 // activations are split in the epilogue.  gfx950's MFMA keeps fp16 subnormal inputs (tools/f16_probe.hip).  Measured
 // against the fp64 oracle this arithmetic is indistinguishable from true fp32 (tests/test_gpu_parity.py).
 // (Round 1's kernel on 32x32x16 tiles, which these definitions were written for, is kept as a record under
-// tools/experiments/; the library ships the 16x16x32 kernels.)
+// tools/experiments/ of commit 27d6e80, pruned in round 6; the library ships the 16x16x32 kernels.)
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -7,7 +7,7 @@
 //     x_{l+1} = x_l + mod_l * act(W_l x_l + b_l)   for l >= 1      (layer 0 and last_layer unchanged)
 // (oracle/siren_oracle.py: siren_forward(residual=True)); the tolerance is the 16-bit format's, not 1e-4.
 //
-// (Round 1's kernel on 32x32x16 tiles, which this header used to hold, is kept as a record under tools/experiments/; same-box
+// (Round 1's kernel on 32x32x16 tiles, which this header used to hold, was kept as a record under tools/experiments/ until round 6 (commit 27d6e80 has it); same-box
 // A/B against its successor: profiles/r4/04_config5_x1n_vs_x1_ab.txt.)
 #pragma once
 #include <hip/hip_runtime.h>

@@ -21,7 +21,7 @@
 //     time (sine, residual, modulation, pack), one step per MFMA gap, plain C++ statements fenced into their gaps by
 //     sched_barriers (the accumulators alternate between two register sets by the unit's parity, so no copies);  a first
 //     form with the epilogue BEHIND its MFMAs was correct and 8-13 % slower than the register-resident kernel
-//     (tools/experiments/siren_trunk_x1w_lite.hip.h, profiles/r4/05_*).
+//     (profiles/r4/05_*; the source: tools/experiments/siren_trunk_x1w_lite.hip.h of commit 27d6e80).
 #pragma once
 #include <hip/hip_runtime.h>
 

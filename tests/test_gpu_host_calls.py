@@ -183,7 +183,7 @@ def test_page_locked_buffers_same_bits_recycled_and_outlive_the_model():
     assert k.value == 1                              # the block is still page-locked memory under the live array ...
     assert np.array_equal(again, ref) and np.array_equal(keep, ref) and np.array_equal(pin, tiles)
     addr, nbytes = again.ctypes.data, again.nbytes
-    del again, pin                                   # ... and goes through msiren_host_free(NULL, ptr) when the last array does
+    del again, pin, ref                              # ... and goes through msiren_host_free(NULL, ptr) when the last array does (ref is a pool block too)
     gc.collect()
     assert pool() is None
     _lib.check(lib.msiren_host_range_kind(ctypes.c_void_p(addr), ctypes.c_size_t(nbytes), ctypes.byref(k)))

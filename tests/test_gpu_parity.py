@@ -936,7 +936,7 @@ def test_buffers_page_locked_in_part_go_through_a_bounce_buffer():
     buffer.  Same bits as on untouched arrays; fully page-locked and fully pageable windows of the same arrays work as ever.  Then the
     case both of whose ENDS are page-locked while the middle is not (two registrations, pageable rows in between): the device address of
     page-locked memory equals its host address here, so the ends alone prove nothing -- the allocation that holds the first byte must
-    hold the last (hipMemGetAddressRange); a kernel let loose on that range would fault on the pageable rows."""
+    hold the last (hipPointerGetAttribute RANGE_START_ADDR / RANGE_SIZE); a kernel let loose on that range would fault on the pageable rows."""
     import ctypes
 
     hip = ctypes.CDLL("libamdhip64.so")

@@ -96,8 +96,8 @@ for cfg in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("sine", "morlet", 
     ok = ok and bad == 0
     if cfg != "sine":
         continue
-    # host-pointer calls (round 5: buffers page-locked per call and used in place, bounce buffers for windows that are page-locked in
-    # part, the pipelined plan from 2400 tiles): two handles in two threads on random windows of ONE pageable input pool and ONE output pool
+    # host-pointer calls (pageable windows copied by the runtime, the mirror's page-locked pool blocks written in place, the pipelined plan
+    # from 2400 tiles): two handles in two threads on random windows of ONE pageable input pool and ONE output pool
     import ctypes
     import threading
 
