@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void modulator_layer_mfma_kernel(ModulatorMfma
 // ARITHMETIC IS THAT OF THE 16 x 16 KERNEL, element for element: the same v_mfma_f32_16x16x4_f32 on the same k groups,
 // the same two accumulation chains per sub-tile (columns 0, 2 / 1, 3 of each 16-k block), K split over the four waves at
 // the same block boundaries, partial sums added in the same order ((r0 + r1) + r2) + r3 + bias -- so an output does not
-// depend on which of the two kernels (i.e. on how large a batch) produced it: bit-identical, tests/test_gpu_split.py.
+// depend on which of the two kernels (i.e. on how large a batch) produced it: bit-identical, tests/test_gpu_host_calls.py.
 // Registers: 32 accumulators + two stages of 4 fragments at 2 x 2 -- under the 96 a kernel may use to run BESIDE the
 // register-resident trunk (tests/test_register_budget.py); LDS 16.5 KB.
 template <int RT, int FT>

@@ -5,7 +5,7 @@
 // and produce the same bits.  A wave here issues half the MFMAs per layer for the same weight-fragment reads, so per
 // coordinate it costs more LDS traffic; what it buys is LATENCY where the chip is not full anyway: small batches
 // (BASELINE configs[0], a single tile) -- twice as many waves share the work, a pass takes about half the time
-// (msiren.hip: launch_trunk_f16x3 selects it when all units fit in one round even as half-units).
+// (launch_dispatch.hip: launch_trunk_f16x3 selects it when all units fit in one round even as half-units).
 // Layout differences from the 32-coordinate kernel: B fragment [s] is k-step s (one column group), accumulators
 // acc[tile parity][sub-tile], the epilogue of a 32-feature tile is 2 parts (sub-tiles) x 2 halves, spread over groups
 // 0, 2, 4, 6 of the next tile.  No sched_group_barrier choreography: this instance is not the throughput path.

@@ -20,7 +20,7 @@
 //   of one coordinate in registers 4g..4g+3, i.e. exactly one float4 of the X image:
 //   the epilogue is  bias -> act -> *mod -> ds_write_b128  with no shuffles.
 //
-// Scaling folded on the host (msiren.hip: pack_trunk): all weights/biases are pre-multiplied by
+// Scaling folded on the host (weights_pack.hip: pack_trunk): all weights/biases are pre-multiplied by
 // w0/(2*pi) (w0_initial for layer 0) so that the accumulator is the sine argument in REVOLUTIONS,
 // the unit v_sin_f32 takes.  Morlet's Gaussian exp(-p^2/2) becomes exp2(cg * r^2).
 #pragma once

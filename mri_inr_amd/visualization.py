@@ -1,0 +1,70 @@
+"""The two summary plots of the reference's evaluation driver, under the reference's names and file names.
+
+``test_mod_siren.py:248-256`` calls ``metrics_boxplot`` and ``metrics_density_plot`` (``src/util/visualization.py:129-165``) on the
+PSNR / SSIM / NRMSE lists of the metric samples: one ``{key}_metrics_boxplot.png`` and one ``{key}_density_plot.png`` per metric in
+the output directory.  The reference draws the density with seaborn's ``kdeplot`` (not in this image: the curve is restated here from
+its published defaults -- a Gaussian kernel density estimate, Scott's bandwidth, 200 grid points from ``min - 3 bw`` to ``max + 3 bw``
+-- with scipy); the box plot is plain matplotlib there as here.  Host-side presentation only: nothing on the hot path.
+"""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+KDE_GRIDSIZE, KDE_CUT = 200, 3.0  # seaborn.kdeplot defaults (gridsize, cut); bandwidth: scipy's "scott", bw_adjust = 1
+
+
+def kde_curve(values):
+    """(x, density) of seaborn's univariate ``kdeplot(values)`` at its defaults, or ``None`` where seaborn draws nothing (fewer than two
+    points, or zero variance: it warns and leaves the axes empty)."""
+    from scipy.stats import gaussian_kde
+
+    v = np.asarray(values, dtype=np.float64).ravel()
+    v = v[np.isfinite(v)]
+    if v.size < 2 or np.var(v) == 0.0:
+        return None
+    kde = gaussian_kde(v, bw_method="scott")
+    bw = float(np.sqrt(kde.covariance.squeeze()))
+    x = np.linspace(v.min() - KDE_CUT * bw, v.max() + KDE_CUT * bw, KDE_GRIDSIZE)
+    return x, kde(x)
+
+
+def _pyplot():
+    import matplotlib
+
+    matplotlib.use("Agg", force=False)
+    import matplotlib.pyplot as plt
+
+    return plt
+
+
+def metrics_boxplot(metrics, output_dir, suffix=None):
+    """One box plot per metric: ``{output_dir}/{key}_metrics_boxplot.png`` (visualization.py:129-146; ``suffix`` is accepted and unused
+    there as well)."""
+    plt = _pyplot()
+    os.makedirs(output_dir, exist_ok=True)
+    for key, value in metrics.items():
+        fig, ax = plt.subplots()
+        ax.boxplot(np.asarray(value, dtype=np.float64))
+        ax.set_xticklabels([key])
+        ax.set_title(key)
+        fig.savefig(os.path.join(output_dir, f"{key}_metrics_boxplot.png"))
+        plt.close(fig)
+
+
+def metrics_density_plot(metrics, output_dir, suffix=None):
+    """One kernel-density plot per metric: ``{output_dir}/{key}_density_plot.png`` (visualization.py:149-165)."""
+    plt = _pyplot()
+    os.makedirs(output_dir, exist_ok=True)
+    for key, value in metrics.items():
+        fig, ax = plt.subplots()
+        curve = kde_curve(value)
+        if curve is not None:
+            ax.plot(curve[0], curve[1])
+            ax.set_ylim(bottom=0)
+        ax.set_ylabel("Density")
+        ax.set_title(key)
+        fig.savefig(os.path.join(output_dir, f"{key}_density_plot.png"))
+        plt.close(fig)

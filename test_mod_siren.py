@@ -14,8 +14,9 @@ load ``config.testing.model_path``, reconstruct ``config.data.metric_samples`` s
     weights (no fastMRI data or checkpoints here); a directory of ``*.npy`` slice pairs
     (``<name>_fully.npy`` / ``<name>_under.npy``) is read otherwise;
   * ``data.visual_samples`` slices get the reference's per-slice image folder (:122-173; ``harness.visual_error``: arrays as
-    ``.npy``, images as ``.png`` without the reference's colour bars); the seaborn box and density plots of the metric
-    samples are not produced.
+    ``.npy``, images as ``.png`` without the reference's colour bars);
+  * the box and density plots of the metric samples (:248-256) come from ``mri_inr_amd/visualization.py``: same function names and file
+    names; the density curve restates seaborn's ``kdeplot`` defaults with scipy (seaborn is not in the image).
 """
 
 from __future__ import annotations
@@ -33,6 +34,7 @@ from mri_inr_amd import ModulatedSiren, load_configuration, model_kwargs, synthe
 from mri_inr_amd.configuration import parse_args  # noqa: E402
 from mri_inr_amd import harness  # noqa: E402
 from mri_inr_amd.harness import image_to_patches, metrics_error, visual_error  # noqa: E402
+from mri_inr_amd.visualization import metrics_boxplot, metrics_density_plot  # noqa: E402
 from mri_inr_amd.weights import load_checkpoint  # noqa: E402
 
 
@@ -120,6 +122,9 @@ def test_mod_siren(config):
         for row in zip(names, psnrs, ssims, nrmses):
             f.write(",".join(str(v) for v in row) + "\n")
     save_metrics_summary(psnrs, ssims, nrmses, output_dir)
+    # Visualize the metrics (reference :248-256)
+    metrics_boxplot({"PSNR": psnrs, "SSIM": ssims, "NRMSE": nrmses}, output_dir)
+    metrics_density_plot({"PSNR": psnrs, "SSIM": ssims, "NRMSE": nrmses}, output_dir)
     print(f"{len(names)} slices scored in {t_gpu:.3f} s host wall (incl. H2D/D2H and the metrics) -> {output_dir}")
     return output_dir
 

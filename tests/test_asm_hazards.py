@@ -347,7 +347,7 @@ def test_no_vector_memory_instruction_of_the_built_library_reads_a_freshly_valu_
     if not (os.path.exists(objdump) and os.path.exists(lib)):
         pytest.skip("needs the built library and llvm-objdump")
     blob = open(lib, "rb").read()
-    # one offload bundle per translation unit (msiren.hip and the k_*.hip kernel units): every gfx950 code object is scanned
+    # one offload bundle per translation unit (the host units and the k_*.hip kernel units): every gfx950 code object is scanned
     text, at, nobj = "", blob.find(b"__CLANG_OFFLOAD_BUNDLE__"), 0
     assert at >= 0
     while at >= 0:

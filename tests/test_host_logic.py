@@ -193,3 +193,28 @@ def test_committed_bench_line_follows_the_contract():
         s = json.loads(open(os.path.join(root, "profiles", "r2", "10_final", name)).read().strip().splitlines()[-1])
         assert s["scaling"] == "strong" and s["n_gpus"] == n and s["config"]["slices_per_step_total"] == 64
         assert abs(s["value"] - 64 * 320 * 320 / (s["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * s["value"]
+
+
+def test_metric_plots_have_the_references_names_and_the_density_is_seaborns_default_kde(tmp_path):
+    """test_mod_siren.py:248-256 of the reference: one box plot and one density plot per metric, named ``{key}_metrics_boxplot.png`` /
+    ``{key}_density_plot.png`` (src/util/visualization.py:145, :164).  The density restates seaborn's ``kdeplot`` defaults (seaborn is
+    not installed): Gaussian KDE with Scott's factor n^(-1/5), 200 points from min - 3 bw to max + 3 bw -- checked against the closed
+    form, not against scipy's own evaluation."""
+    from mri_inr_amd import visualization as vis
+
+    rng = np.random.default_rng(3)
+    m = {"PSNR": list(rng.normal(31.0, 2.0, 40)), "SSIM": list(rng.uniform(0.7, 0.95, 40)), "NRMSE": [0.12] * 40}   # (zero variance: empty axes)
+    vis.metrics_boxplot(m, tmp_path / "out")
+    vis.metrics_density_plot(m, tmp_path / "out", suffix="ignored")
+    for key in m:
+        for name in (f"{key}_metrics_boxplot.png", f"{key}_density_plot.png"):
+            p = tmp_path / "out" / name
+            assert p.exists() and p.stat().st_size > 1000 and p.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n", name
+    v = np.asarray(m["PSNR"])
+    x, d = vis.kde_curve(v)
+    bw = v.std(ddof=1) * len(v) ** (-0.2)                                   # Scott, one dimension
+    assert len(x) == 200 and abs(x[0] - (v.min() - 3 * bw)) < 1e-9 and abs(x[-1] - (v.max() + 3 * bw)) < 1e-9
+    want = np.exp(-0.5 * ((x[:, None] - v[None, :]) / bw) ** 2).sum(1) / (len(v) * bw * np.sqrt(2 * np.pi))
+    assert np.allclose(d, want, rtol=1e-9, atol=0)
+    assert abs(np.trapz(d, x) - 1.0) < 5e-3                                 # (+-3 bw beyond the data holds all but 0.3 % of the mass)
+    assert vis.kde_curve(m["NRMSE"]) is None and vis.kde_curve([1.0]) is None

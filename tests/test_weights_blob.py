@@ -18,7 +18,7 @@ PROG = textwrap.dedent(r"""
     #include "weights_blob.h"
     using namespace msiren;
 
-    static BlobLayout layout_of(int H, int L, int Z) {   // the keys msiren.hip:declare_expected lists, shortened
+    static BlobLayout layout_of(int H, int L, int Z) {   // the keys weights_pack.hip:declare_expected lists, shortened
         BlobLayout e;
         e["grid"] = 576 * 2;
         for (int l = 0; l < L; ++l) {
