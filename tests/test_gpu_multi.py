@@ -294,6 +294,31 @@ def test_bench_two_ranks_rehearsal_reports_what_the_communicator_saw(tmp_path):
     assert d["config"]["hip_runtime"]["torch_bundled"] is False and d["config"]["torch_first"] is False
 
 
+def test_bench_under_torchrun_as_the_driver_starts_it(tmp_path):
+    """The scaling sweep's command line, verbatim: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 --steps K --warmup W` -- two ranks on the one card through the stub RCCL.  Under torchrun the
+    unique id travels through the agent's TCP store (TORCHELASTIC_USE_AGENT_STORE; mri_inr_amd/launch.py), i.e. torch is imported in the
+    rank AFTER libmsiren has brought the system HIP runtime up: the line must say so (torch-free runtime, rccl backend, no fallback) and
+    carry both regions."""
+    from mri_inr_amd.launch import free_port
+
+    stub = _build_rccl_stub(tmp_path)
+    e = {k: v for k, v in os.environ.items() if k not in launch.ENV_KEYS}
+    e.update({"MSIREN_BENCH_ALLOW_SHARED": "1", "MSIREN_RCCL_LIB": stub, "RCCL_STUB_DIR": str(tmp_path)})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["collective_fallback"] is False
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["ranks_hold_identical_weights"] is True
+    assert d["config"]["hip_runtime"]["torch_bundled"] is False            # libmsiren came first: the system runtime
+    assert d["extra"]["configs"]["config3_64_slices_strong"]["slices_per_rank"] == [32, 32]
+    assert d["cpu_baseline"] is None                                       # (rank 0 at N = 1 only)
+
+
 def _bench(args, env=None, timeout=900):
     e = {k: v for k, v in os.environ.items() if k not in launch.ENV_KEYS}
     e.update(env or {})
