@@ -40,31 +40,35 @@ def _pyplot():
     return plt
 
 
+def _one_figure_per_metric(metrics, output_dir, file_suffix, draw):
+    """``draw(ax, key, values)`` on a fresh figure per metric, saved as ``{output_dir}/{key}{file_suffix}``."""
+    plt = _pyplot()
+    os.makedirs(output_dir, exist_ok=True)
+    for key, values in metrics.items():
+        fig, ax = plt.subplots()
+        draw(ax, key, np.asarray(values, dtype=np.float64))
+        ax.set_title(key)
+        fig.savefig(os.path.join(output_dir, key + file_suffix))
+        plt.close(fig)
+
+
 def metrics_boxplot(metrics, output_dir, suffix=None):
     """One box plot per metric: ``{output_dir}/{key}_metrics_boxplot.png`` (visualization.py:129-146; ``suffix`` is accepted and unused
     there as well)."""
-    plt = _pyplot()
-    os.makedirs(output_dir, exist_ok=True)
-    for key, value in metrics.items():
-        fig, ax = plt.subplots()
-        ax.boxplot(np.asarray(value, dtype=np.float64))
+    def draw(ax, key, values):
+        ax.boxplot(values)
         ax.set_xticklabels([key])
-        ax.set_title(key)
-        fig.savefig(os.path.join(output_dir, f"{key}_metrics_boxplot.png"))
-        plt.close(fig)
+
+    _one_figure_per_metric(metrics, output_dir, "_metrics_boxplot.png", draw)
 
 
 def metrics_density_plot(metrics, output_dir, suffix=None):
     """One kernel-density plot per metric: ``{output_dir}/{key}_density_plot.png`` (visualization.py:149-165)."""
-    plt = _pyplot()
-    os.makedirs(output_dir, exist_ok=True)
-    for key, value in metrics.items():
-        fig, ax = plt.subplots()
-        curve = kde_curve(value)
+    def draw(ax, key, values):
+        curve = kde_curve(values)
         if curve is not None:
             ax.plot(curve[0], curve[1])
             ax.set_ylim(bottom=0)
         ax.set_ylabel("Density")
-        ax.set_title(key)
-        fig.savefig(os.path.join(output_dir, f"{key}_density_plot.png"))
-        plt.close(fig)
+
+    _one_figure_per_metric(metrics, output_dir, "_density_plot.png", draw)

@@ -15,7 +15,7 @@ load ``config.testing.model_path``, reconstruct ``config.data.metric_samples`` s
     (``<name>_fully.npy`` / ``<name>_under.npy``) is read otherwise;
   * ``data.visual_samples`` slices get the reference's per-slice image folder (:122-173; ``harness.visual_error``: arrays as
     ``.npy``, images as ``.png`` without the reference's colour bars);
-  * the box and density plots of the metric samples (:248-256) come from ``mri_inr_amd/visualization.py``: same function names and file
+  * the box and density plots of the metric samples (:248-256) come from ``mri_inr_amd/metric_plots.py``: same function names and file
     names; the density curve restates seaborn's ``kdeplot`` defaults with scipy (seaborn is not in the image).
 """
 
@@ -34,7 +34,7 @@ from mri_inr_amd import ModulatedSiren, load_configuration, model_kwargs, synthe
 from mri_inr_amd.configuration import parse_args  # noqa: E402
 from mri_inr_amd import harness  # noqa: E402
 from mri_inr_amd.harness import image_to_patches, metrics_error, visual_error  # noqa: E402
-from mri_inr_amd.visualization import metrics_boxplot, metrics_density_plot  # noqa: E402
+from mri_inr_amd.metric_plots import metrics_boxplot, metrics_density_plot  # noqa: E402
 from mri_inr_amd.weights import load_checkpoint  # noqa: E402
 
 

@@ -200,7 +200,7 @@ def test_metric_plots_have_the_references_names_and_the_density_is_seaborns_defa
     ``{key}_density_plot.png`` (src/util/visualization.py:145, :164).  The density restates seaborn's ``kdeplot`` defaults (seaborn is
     not installed): Gaussian KDE with Scott's factor n^(-1/5), 200 points from min - 3 bw to max + 3 bw -- checked against the closed
     form, not against scipy's own evaluation."""
-    from mri_inr_amd import visualization as vis
+    from mri_inr_amd import metric_plots as vis
 
     rng = np.random.default_rng(3)
     m = {"PSNR": list(rng.normal(31.0, 2.0, 40)), "SSIM": list(rng.uniform(0.7, 0.95, 40)), "NRMSE": [0.12] * 40}   # (zero variance: empty axes)
