@@ -292,10 +292,12 @@ static int msiren_forward_mods_impl(msiren_handle h, const float* mods_host, int
     const HostDst dst(out_host, no);
     HOSTBUF_OK(src);
     HOSTBUF_OK(dst);
+    DrainOnExit drain(h);
     HIPCHK(hipMemcpyAsync(h->sc[h->cur].mods.p, src.as<float>(), nm, hipMemcpyHostToDevice, h->sc[h->cur].s));
     if ((rc = launch_trunk(h, (const float*)h->sc[h->cur].mods.p, B, (float*)h->ws_out.p))) return rc;
     HIPCHK(hipMemcpyAsync(dst.as<float>(), h->ws_out.p, no, hipMemcpyDeviceToHost, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
+    drain.disarm();
     dst.finish();
     return 0;
 }
@@ -327,11 +329,13 @@ static int msiren_forward_latent_impl(msiren_handle h, const float* z_host, int6
     HOSTBUF_OK(src);
     HOSTBUF_OK(dst);
     HOSTBUF_OK(dst_mods);
+    DrainOnExit drain(h);
     HIPCHK(hipMemcpyAsync(h->sc[h->cur].latent.p, src.as<float>(), nz, hipMemcpyHostToDevice, h->sc[h->cur].s));
     if ((rc = forward_latent_dev(h, (const float*)h->sc[h->cur].latent.p, B, (float*)h->ws_out.p, (float*)h->sc[h->cur].mods.p))) return rc;
     HIPCHK(hipMemcpyAsync(dst.as<float>(), h->ws_out.p, no, hipMemcpyDeviceToHost, h->sc[h->cur].s));
     if (mods_out_host) HIPCHK(hipMemcpyAsync(dst_mods.as<float>(), h->sc[h->cur].mods.p, nm, hipMemcpyDeviceToHost, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
+    drain.disarm();
     dst.finish();
     dst_mods.finish();
     return 0;
@@ -373,10 +377,12 @@ int msiren_encode_tiles(msiren_handle h, const float* tiles_host, int64_t B, flo
     const HostDst dst(z_host, nz);
     HOSTBUF_OK(src);
     HOSTBUF_OK(dst);
+    DrainOnExit drain(h);
     HIPCHK(hipMemcpyAsync(h->ws_tiles.p, src.as<float>(), nt, hipMemcpyHostToDevice, c.s));
     if ((rc = launch_encoder(h, (const float*)h->ws_tiles.p, B, (float*)c.latent.p))) return rc;
     HIPCHK(hipMemcpyAsync(dst.as<float>(), c.latent.p, nz, hipMemcpyDeviceToHost, c.s));
     HIPCHK(hipStreamSynchronize(c.s));
+    drain.disarm();
     dst.finish();
     return 0;
 }
@@ -393,10 +399,12 @@ int msiren_modulate(msiren_handle h, const float* z_host, int64_t B, float* mods
     const HostDst dst(mods_host, nm);
     HOSTBUF_OK(src);
     HOSTBUF_OK(dst);
+    DrainOnExit drain(h);
     HIPCHK(hipMemcpyAsync(c.latent.p, src.as<float>(), nz, hipMemcpyHostToDevice, c.s));
     if ((rc = launch_modulator(h, (const float*)c.latent.p, B, (float*)c.mods.p))) return rc;
     HIPCHK(hipMemcpyAsync(dst.as<float>(), c.mods.p, nm, hipMemcpyDeviceToHost, c.s));
     HIPCHK(hipStreamSynchronize(c.s));
+    drain.disarm();
     dst.finish();
     return 0;
 }
@@ -632,8 +640,10 @@ int msiren_memcpy_h2d(msiren_handle h, void* dst_dev, const void* src_host, size
     if ((rc = sync_all(h))) return rc;
     const HostSrc src(src_host, bytes);
     HOSTBUF_OK(src);
+    DrainOnExit drain(h);
     HIPCHK(hipMemcpyAsync(dst_dev, src.as<void>(), bytes, hipMemcpyHostToDevice, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
+    drain.disarm();
     return 0;
 }
 
@@ -644,8 +654,10 @@ int msiren_memcpy_d2h(msiren_handle h, void* dst_host, const void* src_dev, size
     if ((rc = sync_all(h))) return rc;
     const HostDst dst(dst_host, bytes);
     HOSTBUF_OK(dst);
+    DrainOnExit drain(h);
     HIPCHK(hipMemcpyAsync(dst.as<void>(), src_dev, bytes, hipMemcpyDeviceToHost, h->sc[h->cur].s));
     HIPCHK(hipStreamSynchronize(h->sc[h->cur].s));
+    drain.disarm();
     dst.finish();
     return 0;
 }
