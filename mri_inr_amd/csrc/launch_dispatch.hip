@@ -642,8 +642,10 @@ int launch_encoder(msiren_ctx* h, const float* tiles_dev, int64_t B, float* z_de
     if (h->em_enc) return launch_prologue_f16x3(h, tiles_dev, nullptr, B, z_dev, nullptr);
     hipStream_t s = h->sc[h->cur].s;
     h->enc.plan = h->plan;
-    // small batches are launch-latency bound: one fused per-tile kernel instead of three launches
-    if (h->Z % 16 != 0 || B < 48) {
+    // Shapes the MFMA Linear kernels do not take (latent_dim not a multiple of 16): one fused per-tile kernel.  (Until round 6 batches
+    // below 48 tiles took it as well, for two launches less -- but its VALU sums run in another order than the MFMA kernels', so an
+    // fp32 handle's latent depended in the last bits on the size of the batch a tile came in; the split-fp16 prologue never had that seam.)
+    if (h->Z % 16 != 0) {
         hipLaunchKernelGGL(msiren::encoder_kernel, dim3((unsigned)B), dim3(256), 0, s, h->enc, tiles_dev, z_dev);
         HIPCHK(hipGetLastError());
         return 0;

@@ -258,6 +258,21 @@ def test_modulator_kernels_vs_oracle(H, Z, L, B):
     check(out.reshape(B, -1), ref)
 
 
+@pytest.mark.parametrize("B", [1, 50])
+def test_encoder_with_a_latent_size_the_mfma_kernels_do_not_take(B):
+    """latent_dim = 24 (not a multiple of 16): the fused per-tile encoder kernel (VALU; encoder_modulator.hip.h) and the VALU Modulator
+    kernel are what runs -- the only shapes they still serve since round 6.  Latent and output against the fp64 oracle
+    (siren_encoder.py:503-512, 565-577; modulated_siren.py:325-343)."""
+    H, Z, L = 100, 24, 3
+    sd = syn.make_state_dict(seed=17, dim_hidden=H, num_layers=L, latent_dim=Z, trained_like=True)
+    m = make_model(sd, H=H, L=L, Z=Z)
+    tiles = np.random.default_rng(B).random((B, 32, 32), dtype=np.float32)
+    z = m.encoder(tiles)
+    assert z.shape == (B, Z) and nerr(z, orc.encoder_forward(sd, tiles, dtype=np.float64)) < 1e-5
+    check(m(tiles), orc.modulated_siren_forward(sd, tiles, num_layers=L, dtype=np.float64))
+    assert np.array_equal(m.encoder(tiles[:1]), z[:1])            # one kernel at every batch size: same bits
+
+
 @pytest.mark.parametrize("L,S,B", [(5, 24, 400), (5, 24, 7), (2, 24, 5), (3, 10, 9), (4, 24, 1030), (6, 8, 33), (8, 24, 50),
                                    (11, 24, 20)])
 def test_f16x3_trunk_vs_oracle_shapes(L, S, B):
