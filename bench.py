@@ -478,7 +478,7 @@ def main():
     strong = None
     default_sizing = not args.total_slices and args.slices == 1
     if world > 1 and default_sizing and not args.no_strong and not deep and args.pipeline == "forward" and not args.brain_mask:
-        strong = strong_config3(model, group, lib, h, _lib, syn, shard_range, rank, world, args, device_sync, fence)
+        strong = strong_config3(model, group, lib, h, _lib, syn, shard_range, rank, world, args, device_sync, fence, backend)
 
     px_per_step = n_total * 320 * 320
     value = px_per_step * args.steps / elapsed / 1e6
@@ -788,7 +788,7 @@ def n1_reference():
     return None, None
 
 
-def strong_config3(model, group, lib, h, _lib, syn, shard_range, rank, world, args, device_sync, fence, total=64, steps=24, warmup=3):
+def strong_config3(model, group, lib, h, _lib, syn, shard_range, rank, world, args, device_sync, fence, backend, total=64, steps=24, warmup=3):
     """BASELINE configs[2] behind the weak region of a multi-rank run: a fixed batch of 64 slices per step, contiguous slice shards
     (dist.shard_range), no data-path collective; barrier + MAX over ranks around the timed steps like the headline region.
     efficiency_vs_n1 = value / (world x the stored N = 1 value of the same workload)."""
@@ -830,7 +830,7 @@ def strong_config3(model, group, lib, h, _lib, syn, shard_range, rank, world, ar
     return {"workload": f"BASELINE configs[2]: batch of {total} slices = {total * 400} tiles per step, contiguous slice shards over {world} ranks "
                         f"(strong scaling), tiles and outputs resident in HBM, {args.streams} streams per rank",
             "value": value, "unit": "Mpixel/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup, "scaling": "strong",
-            "n_gpus": world, "slices_per_rank": per_rank, "rccl_ranks": comm_ranks,
+            "n_gpus": world, "slices_per_rank": per_rank, "rccl_ranks": comm_ranks if backend in ("rccl", "nccl") else None, "comm_ranks": comm_ranks,
             "n1_reference_value": ref, "n1_reference_source": src,
             "efficiency_vs_n1": (value / (world * ref)) if ref else None,
             "note": "the scaling claim of the north star (>= 0.9 linear at 8 GPUs) is about THIS number; the line's `value` is the weak "

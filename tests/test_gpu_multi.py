@@ -383,6 +383,7 @@ def test_bench_gpus2_starts_its_own_ranks_gloo_rehearsal_on_one_card():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["slices_per_step_total"] == 2
     assert abs(d["value"] - 2 * 320 * 320 / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
     assert d["extra"]["configs"]["config3_64_slices_strong"]["slices_per_rank"] == [32, 32]      # the strong region rides along
+    assert d["extra"]["configs"]["config3_64_slices_strong"]["rccl_ranks"] is None and d["extra"]["configs"]["config3_64_slices_strong"]["comm_ranks"] == 2
     assert d["config"]["hip_runtime"]["torch_bundled"] is True                                    # (gloo: torch came first)
     s = _bench(["--gpus", "2", "--total-slices", "6", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"], env)
     assert s["n_gpus"] == 2 and s["scaling"] == "strong"
