@@ -597,6 +597,8 @@ def main():
             # torch's bundled one behind --torch-first / the torch backends
             "hip_runtime": _lib.runtime_info(),
             "torch_first": bool(args.torch_first or tgroup is not None),
+            # (flat copies: records that keep only the scalars of `config` still carry them)
+            "hip_runtime_version": _lib.runtime_info()["hip_runtime_version"], "libamdhip64": _lib.runtime_info()["libamdhip64"],
         },
         "roofline": roof,
         "device_ms_per_step": dev_ms.value / args.steps,
@@ -617,6 +619,8 @@ def main():
         result.setdefault("extra", {}).setdefault("configs", {})["config3_64_slices_strong"] = strong
         result["config"]["also_measured"] = {"config3_64_slices_strong": {k: strong[k] for k in
                                              ("value", "unit", "ms_per_step", "slices_per_rank", "efficiency_vs_n1", "n1_reference_value", "rccl_ranks")}}
+        result["config"].update({"config3_strong_mpixel_s": strong["value"], "config3_strong_ms_per_step": strong["ms_per_step"],
+                                 "config3_strong_efficiency_vs_n1": strong["efficiency_vs_n1"], "config3_n1_reference_mpixel_s": strong["n1_reference_value"]})
 
     if rank == 0:
         if args.check and args.pipeline == "reconstruct":
@@ -647,6 +651,7 @@ def main():
                 "what": "numpy tiles (400,32,32) on the host -> numpy (400,24,24) on the host through msiren_forward_tiles, one 320x320 slice per "
                         "synchronous call, one stream, PCIe copies inside; outputs from the mirror's page-locked pool (its default)"}
             result["config"].setdefault("also_measured", {})["host_to_host_mpixel_s"] = ex["host_to_host_mpixel_s"]
+            result["config"]["host_to_host_mpixel_s"] = ex["host_to_host_mpixel_s"]
             if args.pipeline == "forward" and not args.brain_mask and not args.total_slices and args.slices == 1 \
                     and args.activation == "sine" and args.precision == "f16x3":
                 # the default (driver-run) line also carries every other BASELINE configuration, measured in this process
@@ -661,9 +666,12 @@ def main():
                                       "kernel_alone_frac": f32["kernel_alone_frac"], "timed_frac": f32["timed_frac"],
                                       "kernel_alone_avg_launch_ms": f32["kernel_alone_avg_launch_ms"], "command": f32["command"]}
                     result["roofline"]["fp32_trunk"] = {k: result["fp32"][k] for k in ("value", "kernel", "kernel_alone_frac", "timed_frac", "peak_tflops")}
+                    result["roofline"].update({"fp32_trunk_mpixel_s": f32["value"], "fp32_trunk_kernel_alone_frac": f32["kernel_alone_frac"],
+                                               "fp32_trunk_timed_frac": f32["timed_frac"]})
                 c3 = result["extra"]["configs"].get("config3_64_slices_n1", {})
                 if "value" in c3:
                     result["config"].setdefault("also_measured", {})["config3_64_slices_n1"] = {"value": c3["value"], "ms_per_step": c3["ms_per_step"]}
+                    result["config"]["config3_64_slices_n1_mpixel_s"] = c3["value"]
         if world == 1 and not args.no_cpu_baseline and not deep:
             result["cpu_baseline"] = cpu_baseline(sd, tiles400, args.activation, args.cpu_seconds)
         else:

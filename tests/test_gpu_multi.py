@@ -291,6 +291,7 @@ def test_bench_two_ranks_rehearsal_reports_what_the_communicator_saw(tmp_path):
     assert abs(st["efficiency_vs_n1"] - st["value"] / (2 * st["n1_reference_value"])) < 1e-9
     assert 0.3 < st["efficiency_vs_n1"] < 0.75        # two ranks SHARE one card here: about half, never the claim itself
     assert d["config"]["also_measured"]["config3_64_slices_strong"]["value"] == st["value"]
+    assert d["config"]["config3_strong_mpixel_s"] == st["value"] and d["config"]["config3_strong_efficiency_vs_n1"] == st["efficiency_vs_n1"]
     assert d["config"]["hip_runtime"]["torch_bundled"] is False and d["config"]["torch_first"] is False
 
 
@@ -354,6 +355,8 @@ def test_bench_single_gpu_line_carries_roofline_cpu_baseline_and_extras():
     # SURVEY section 8(d)'s primary region and the strict-fp32 trunk as top-level keys (and inside config / roofline, which the driver keeps)
     assert d["host_to_host"]["value"] == ex["host_to_host_mpixel_s"] and d["host_to_host"]["unit"] == "Mpixel/s"
     assert d["config"]["also_measured"]["host_to_host_mpixel_s"] == ex["host_to_host_mpixel_s"]
+    assert d["config"]["host_to_host_mpixel_s"] == ex["host_to_host_mpixel_s"] and d["roofline"]["fp32_trunk_mpixel_s"] == d["fp32"]["value"]
+    assert d["config"]["hip_runtime_version"] == d["config"]["hip_runtime"]["hip_runtime_version"] and d["config"]["config3_64_slices_n1_mpixel_s"] > 0
     assert d["fp32"]["kernel"] == "siren_trunk_f32_kernel<256,0,0>" and d["fp32"]["value"] == ex["configs"]["fp32_trunk"]["value"]
     assert 0.5 < d["fp32"]["kernel_alone_frac"] < 1.0 and d["roofline"]["fp32_trunk"]["kernel_alone_frac"] == d["fp32"]["kernel_alone_frac"]
     rt = d["config"]["hip_runtime"]

@@ -188,6 +188,30 @@ def test_committed_bench_line_follows_the_contract():
     traffic = json.load(open(os.path.join(root, "profiles", "r5", "traffic.json")))
     assert {k["kernel"] for k in traffic["kernels"]} >= {"siren_trunk_f16x3n_kernel<0,3,5>", "siren_trunk_f16x3w_kernel<0,4>", "latent_mods_f16x3_kernel<2,2,8,3>",
                                                           "siren_trunk_x1w_kernel<1,0,1>"}
+    # round 6's line (profiles/r6/06_final/bench_driver_like.json, the driver's command on the final tree): SURVEY 8(d)'s primary region and the
+    # strict-fp32 trunk as top-level keys AND as scalars inside config / roofline (a record that keeps only their scalars still has them); the
+    # HIP runtime the library was bound to is named; this round's PMC record is the traffic source of the headline kernel
+    l6 = json.loads(open(os.path.join(root, "profiles", "r6", "06_final", "bench_driver_like.json")).read().strip().splitlines()[-1])
+    assert l6["steps"] == 20 and l6["warmup"] == 5 and l6["n_gpus"] == 1 and l6["scaling"] == "weak" and l6["vs_baseline"] is None
+    assert abs(l6["value"] - 320 * 320 / (l6["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * l6["value"]
+    r6, c6 = l6["roofline"], l6["config"]
+    assert r6["kernel"] == "siren_trunk_f16x3n_kernel<0,3,5>" and abs(r6["frac"] - r6["achieved"] / r6["peak"]) < 1e-9 and 0.5 < r6["frac"] < 0.6
+    assert 250 < l6["host_to_host"]["value"] == c6["host_to_host_mpixel_s"] == l6["extra"]["host_to_host_mpixel_s"] < l6["value"]
+    assert l6["fp32"]["kernel"] == "siren_trunk_f32_kernel<256,0,0>" and 100 < l6["fp32"]["value"] == r6["fp32_trunk_mpixel_s"] < 115
+    assert 0.7 < l6["fp32"]["kernel_alone_frac"] == r6["fp32_trunk_kernel_alone_frac"] < 0.85 and l6["fp32"]["peak_tflops"] == 157.3
+    assert c6["hip_runtime"]["torch_bundled"] is False and c6["hip_runtime_version"] == c6["hip_runtime"]["built_against_hip"] and c6["torch_first"] is False
+    assert c6["config3_64_slices_n1_mpixel_s"] == l6["extra"]["configs"]["config3_64_slices_n1"]["value"] > 300
+    t6 = json.load(open(os.path.join(root, "profiles", "r6", "traffic.json")))
+    assert {k["kernel"] for k in t6["kernels"]} == {"siren_trunk_f32_kernel<256,0,0>", "siren_trunk_f16x3n_kernel<0,3,5>"}
+    for k in t6["kernels"]:
+        assert abs(k["bytes_per_launch"] - (2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024) < 1 and os.path.exists(os.path.join(root, k["source"]))
+    # both runtimes side by side (profiles/r6/02_lines): the same command, torch-free and --torch-first, within 1 % of each other
+    a, b = (json.loads(open(os.path.join(root, "profiles", "r6", "02_lines", n)).read().strip().splitlines()[-1]) for n in ("bench_default.json", "bench_torch_first.json"))
+    assert a["config"]["hip_runtime"]["torch_bundled"] is False and b["config"]["hip_runtime"]["torch_bundled"] is True
+    assert a["config"]["hip_runtime"]["hip_runtime_version"] != b["config"]["hip_runtime"]["hip_runtime_version"]
+    assert abs(a["value"] - b["value"]) < 0.01 * a["value"] and abs(a["fp32"]["value"] - b["fp32"]["value"]) < 0.01 * a["fp32"]["value"]
+    ref = json.load(open(os.path.join(root, "profiles", "r6", "n1_reference.json")))["config3_64_slices_n1"]
+    assert ref["value"] == a["extra"]["configs"]["config3_64_slices_n1"]["value"]
     # the strong-scaling form of BASELINE configs[2] on one GPU, and its 4-rank rehearsal on one card
     for name, n in (("bench_strong64_n1.json", 1), ("bench_strong64_gloo4_one_card.json", 4)):
         s = json.loads(open(os.path.join(root, "profiles", "r2", "10_final", name)).read().strip().splitlines()[-1])
