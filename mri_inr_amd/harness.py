@@ -202,18 +202,14 @@ def metrics_error(model, fully_sampled, undersampled, img_information, device, o
     return calculate_psnr(full, rec), calculate_ssim(full, rec), calculate_nrmse(full, rec)
 
 
-def _unit_range(a):
-    lo, hi = float(a.min()), float(a.max())
-    return (a - lo) / (hi - lo) if hi > lo else np.zeros_like(a)
-
-
 def visual_error(model, output_dir, filename, fully_sampled, undersampled, img_information, device, outer_patch_size,
                  inner_patch_size, siren_patch_size):
     """The reconstruction of one slice next to what it came from, as images.  error.py:104-183: black-tile filter ->
     model -> zeros re-inserted -> weighted fold; the undersampled and fully-sampled tiles folded with the plain overlap
     average; then ``{filename}_reconstructed / _undersampled / _fully_sampled / _difference / _comparison`` under
-    ``output_dir``.  Every array is written as ``.npy`` (what a test can check) and, where matplotlib is importable, as
-    ``.png`` (min-max scaled; the difference |fully - reconstructed| in viridis, as the reference)."""
+    ``output_dir`` and ``{filename}_error.txt`` with the slice's PSNR / SSIM / NRMSE (error.py:160-197).  Every array is written as ``.npy``
+    (what a test can check) and, where matplotlib is importable, as ``.png`` through the mirrors of the reference's ``save_image`` /
+    ``save_image_comparison`` (metric_plots.py: min-max scaled, colour bar, the difference |fully - reconstructed| in viridis)."""
     import os
 
     if siren_patch_size != model.siren_patch_size:
@@ -228,13 +224,18 @@ def visual_error(model, output_dir, filename, fully_sampled, undersampled, img_i
     os.makedirs(output_dir, exist_ok=True)
     for kind, a in images.items():
         np.save(os.path.join(output_dir, f"{filename}_{kind}.npy"), a)
+    # the three scores of the slice, as the reference writes them (error.py:185-197)
+    with open(os.path.join(output_dir, f"{filename}_error.txt"), "w") as f:
+        f.write(f"PSNR: {calculate_psnr(full, rec)}\n")
+        f.write(f"SSIM: {calculate_ssim(full, rec)}\n")
+        f.write(f"NRMSE: {calculate_nrmse(full, rec)}\n")
     try:
-        from matplotlib import image as mpl_image
+        from . import metric_plots as mp
+
+        mp._pyplot()
     except ImportError:
         return images
-    for kind, a in images.items():
-        mpl_image.imsave(os.path.join(output_dir, f"{filename}_{kind}.png"), _unit_range(a),
-                         cmap="viridis" if kind == "difference" else "gray", vmin=0.0, vmax=1.0)
-    side_by_side = np.concatenate([_unit_range(images[k]) for k in ("undersampled", "fully_sampled", "reconstructed", "difference")], axis=1)
-    mpl_image.imsave(os.path.join(output_dir, f"{filename}_comparison.png"), side_by_side, cmap="gray", vmin=0.0, vmax=1.0)
+    for kind, a in images.items():   # save_image x 4 (the difference in viridis), then save_image_comparison: error.py:160-183
+        mp.save_image(a, f"{filename}_{kind}", output_dir, cmap="viridis" if kind == "difference" else "gray")
+    mp.save_image_comparison(full, under, rec, os.path.join(output_dir, f"{filename}_comparison"))
     return images

@@ -14,7 +14,7 @@ load ``config.testing.model_path``, reconstruct ``config.data.metric_samples`` s
     weights (no fastMRI data or checkpoints here); a directory of ``*.npy`` slice pairs
     (``<name>_fully.npy`` / ``<name>_under.npy``) is read otherwise;
   * ``data.visual_samples`` slices get the reference's per-slice image folder (:122-173; ``harness.visual_error``: arrays as
-    ``.npy``, images as ``.png`` without the reference's colour bars);
+    ``.npy``, images as ``.png`` through mirrors of the reference's ``save_image`` / ``save_image_comparison``, the slice's ``_error.txt``);
   * the box and density plots of the metric samples (:248-256) come from ``mri_inr_amd/metric_plots.py``: same function names and file
     names; the density curve restates seaborn's ``kdeplot`` defaults with scipy (seaborn is not in the image).
 """

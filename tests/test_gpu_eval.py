@@ -114,6 +114,9 @@ def test_eval_driver_artefacts_and_scores(tmp_path):
     assert np.allclose(np.load(vis / "a_square_difference.npy"), np.abs(ref_full - got_rec), atol=1e-6)
     for kind in ("reconstructed", "undersampled", "fully_sampled", "difference", "comparison"):
         assert (vis / f"a_square_{kind}.png").stat().st_size > 0
+    err = dict(l.split(": ") for l in (vis / "a_square_error.txt").read_text().splitlines())       # error.py:185-197
+    assert list(err) == ["PSNR", "SSIM", "NRMSE"]
+    assert abs(float(err["PSNR"]) - metrics.calculate_psnr(ref_full, got_rec)) < 1e-9 and abs(float(err["NRMSE"]) - metrics.calculate_nrmse(ref_full, got_rec)) < 1e-12
     # the box and density plots of the metric samples, under the reference's file names (test_mod_siren.py:248-256, visualization.py:145, :164)
     for key in ("PSNR", "SSIM", "NRMSE"):
         for name in (f"{key}_metrics_boxplot.png", f"{key}_density_plot.png"):

@@ -242,3 +242,22 @@ def test_metric_plots_have_the_references_names_and_the_density_is_seaborns_defa
     assert np.allclose(d, want, rtol=1e-9, atol=0)
     assert abs(getattr(np, "trapezoid", getattr(np, "trapz", None))(d, x) - 1.0) < 5e-3                                 # (+-3 bw beyond the data holds all but 0.3 % of the mass)
     assert vis.kde_curve(m["NRMSE"]) is None and vis.kde_curve([1.0]) is None
+
+
+def test_image_writers_mirror_the_references_save_image_and_comparison(tmp_path):
+    """src/util/visualization.py:44-110 as visual_error uses them (error.py:160-183): `save_image` writes `{dir}/{filename}.png` of the
+    min-max normalised image with a colour bar, `save_image_comparison` four titled panels; a constant image does not produce NaNs."""
+    from mri_inr_amd import metric_plots as mp
+
+    rng = np.random.default_rng(5)
+    full = rng.random((48, 40)).astype(np.float32) * 3e-5           # fastMRI-like magnitudes: nothing is visible without the normalisation
+    under, rec = full * 0.8, full + 1e-6
+    n = mp.normalize_scan(full)
+    assert n.min() == 0.0 and n.max() == 1.0 and np.allclose(n, (full - full.min()) / (full.max() - full.min()))
+    assert not np.isnan(mp.normalize_scan(np.full((4, 4), 2.0))).any()
+    mp.save_image(full[None], "slice_fully_sampled", tmp_path / "v")             # (1, H, W) as the reference's tensors: squeezed
+    mp.save_image(np.abs(full - rec), "slice_difference", tmp_path / "v", cmap="viridis")
+    mp.save_image_comparison(full, under, rec, tmp_path / "v" / "slice_comparison")
+    for name in ("slice_fully_sampled.png", "slice_difference.png", "slice_comparison.png"):
+        p = tmp_path / "v" / name
+        assert p.exists() and p.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n" and p.stat().st_size > 2000, name
