@@ -90,6 +90,11 @@ int main(int argc, char** argv) {
     double flops = 0.0;
     msiren_flops_per_coord(h, &flops);
     printf("ok: %lld patches x %d coordinates, %.0f FLOP per coordinate\n", (long long)B, P, flops);
+    /* which HIP runtime the library's calls ran on: a C host has no torch in the process, so the system one */
+    int32_t rt = 0, built = 0;
+    char path[512];
+    msiren_runtime_info(&rt, &built, NULL, path, sizeof path);
+    printf("hip runtime %d (library built against %d): %s\n", rt, built, path);
     msiren_destroy(h);
     free(mods);
     free(out);

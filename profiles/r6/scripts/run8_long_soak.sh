@@ -1,0 +1,10 @@
+#!/bin/bash
+# Round 6, lease 8: tools/soak.py 120, every configuration, torch imported first (bundled HIP 7.0 runtime -- the runtime the round-5 fault was seen on).
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/r6/soak2; rm -rf $out; mkdir -p $out
+timeout -k 10 1000 python3 -c "
+import sys, runpy, torch
+torch.cuda.init()
+sys.argv = ['tools/soak.py', '120']
+runpy.run_path('tools/soak.py', run_name='__main__')
+" 2>&1 | grep -v amdgpu.ids | tee $out/soak_torch_first_all.txt

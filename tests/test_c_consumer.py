@@ -71,6 +71,7 @@ def test_c_consumer_reproduces_the_reference_fixture(tmp_path):
     w, m, o = _write_inputs(tmp_path, sd, mods)
     res = subprocess.run([exe, w, m, o], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
+    assert "hip runtime" in res.stdout and "/torch/lib/" not in res.stdout      # a torch-free host: the system runtime (msiren_runtime_info)
     with open(o, "rb") as f:
         B, P = struct.unpack("<ii", f.read(8))
         out = np.frombuffer(f.read(), dtype=np.float32).reshape(B, P)
