@@ -261,3 +261,28 @@ def test_image_writers_mirror_the_references_save_image_and_comparison(tmp_path)
     for name in ("slice_fully_sampled.png", "slice_difference.png", "slice_comparison.png"):
         p = tmp_path / "v" / name
         assert p.exists() and p.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n" and p.stat().st_size > 2000, name
+
+
+def test_every_environment_knob_is_in_the_design_table_and_there_are_at_most_twelve():
+    """DESIGN.md section 9 is THE list of environment knobs (round 6 cut 30 to 12).  Every MSIREN_* variable the library (getenv in
+    mri_inr_amd/csrc), the Python package and bench.py read must be a row of that table, and nothing else may be."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    for dp, _, files in os.walk(os.path.join(root, "mri_inr_amd")):
+        if os.sep + "build" in dp or "__pycache__" in dp:
+            continue
+        for f in files:
+            if f.endswith((".hip", ".h", ".py")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                read |= set(re.findall(r'getenv\("(MSIREN_[A-Z0-9_]+)"\)', src))
+                read |= set(re.findall(r'env(?:iron)?(?:\.get)?[\(\[]\s*"(MSIREN_[A-Z0-9_]+)"', src))
+    src = open(os.path.join(root, "bench.py")).read()
+    read |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(MSIREN_[A-Z0-9_]+)"', src))
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    sec = design[design.index("## 9. Environment knobs"):design.index("## 10.")]
+    table = set(re.findall(r"^\| `(MSIREN_[A-Z0-9_]+)", sec, re.M))
+    assert read == table, (sorted(read - table), sorted(table - read))
+    assert len(table) <= 12, sorted(table)
